@@ -1,0 +1,115 @@
+"""Seeded input generators shared by the golden-vector script and the tests.
+
+Each generator reproduces the set-up of one of the reference's own tests (same seed,
+same order of RandomState calls), so that the inputs need not be stored:
+``np.random.RandomState`` legacy streams are frozen by NumPy's compatibility policy.
+"""
+
+import numpy as np
+
+BACKGROUND_COLS = [0, 1, 17, 99, 100, 312]
+CFG1_COLS = [0, 1, 2, 3, 511, 1024, 2047]
+
+
+def complex_normal(rs, size):
+    """Circularly symmetric Gaussian, as reference test/__init__.py:31-42."""
+    return rs.normal(0.0, 1.0, size) + 1j * rs.normal(0.0, 1.0, size)
+
+
+def abs_probe():
+    """complex64 probe values for numpy's abs: wide dynamic range plus specials."""
+    rs = np.random.RandomState(5)
+    n = 4096
+    re = rs.standard_normal(n) * np.exp(rs.uniform(-20, 20, n))
+    im = rs.standard_normal(n) * np.exp(rs.uniform(-20, 20, n))
+    z = (re + 1j * im).astype(np.complex64)
+    specials = np.array(
+        [
+            0, 1, 1j, -1, -1j, complex(-0.0, -0.0), complex(3, 4), complex(1e-45, 1e-45),
+            complex(1e-45, 0), complex(3e38, 3e38), complex(3e38, 1e38), complex(1e-30, 1e-38),
+            complex(np.inf, 1), complex(1, -np.inf), complex(np.inf, np.inf),
+            complex(1e-20, 1e20), complex(1.1754944e-38, 1.1754944e-38),
+        ],
+        dtype=np.complex64,
+    )  # fmt: skip
+    return np.concatenate([z, specials])
+
+
+def background_case():
+    """reference test/rfi/test_background.py:33-45 (417x313, 10 % flags, block of 4s)."""
+    shape = (417, 313)
+    rs = np.random.RandomState(seed=1)
+    vis_big = complex_normal(rs, size=shape).astype(np.complex64)
+    flags_big = (rs.random_sample(shape) < 0.1).astype(np.uint8)
+    flags_big[100:110, 0:100] = 4
+    return vis_big, flags_big
+
+
+def noise_case():
+    """reference test/rfi/test_noise_est.py:39-43 (117x273 standard normal float32)."""
+    rs = np.random.RandomState(seed=1)
+    return rs.standard_normal((117, 273)).astype(np.float32)
+
+
+def threshold_case():
+    """reference test/rfi/test_threshold.py:32-41 (117x273, 25 % spikes of +200)."""
+    shape = (117, 273)
+    rs = np.random.RandomState(seed=1)
+    spikes = rs.random_sample(shape) < 0.25
+    deviations = rs.standard_normal(shape).astype(np.float32) * 10.0
+    deviations[spikes] += 200.0
+    return deviations, spikes
+
+
+def flagger_case():
+    """reference test/rfi/test_flagger.py:36-52 (117x131, 1/16 RFI, 1/16 input flags = 2)."""
+    shape = (117, 131)
+    rs = np.random.RandomState(seed=1)
+    vis = complex_normal(rs, size=shape)
+    spikes = rs.random_sample(shape) < 1.0 / 16.0
+    spikes = spikes.astype(np.uint8)
+    rfi_amp = rs.random_sample(shape) * 20.0 + 50.0
+    rfi_phase = rs.random_sample(shape) * (2j * np.pi)
+    rfi = rfi_amp * np.exp(rfi_phase)
+    vis += spikes * rfi
+    vis = vis.astype(np.complex64)
+    input_flags = (rs.random_sample(shape) < 1.0 / 16.0).astype(np.uint8) * 2
+    return vis, spikes, input_flags
+
+
+def generate_data(channels, baselines, seed=1):
+    """reference scripts/rfiflagtest.py:35-44."""
+    rs = np.random.RandomState(seed=seed)
+    out = np.empty((channels, baselines), np.complex64)
+    for i in range(channels):
+        real = rs.standard_normal(size=baselines).astype(np.float32)
+        imag = rs.standard_normal(size=baselines).astype(np.float32)
+        out[i] = real + 1j * imag
+    return out
+
+
+def add_rfi(vis, seed=3, fraction=1.0 / 16.0):
+    """Spikes as in test/rfi/test_flagger.py:42-50, row by row to bound memory."""
+    rs = np.random.RandomState(seed=seed)
+    out = np.array(vis, dtype=np.complex64, copy=True)
+    for i in range(vis.shape[0]):
+        s = rs.random_sample(vis.shape[1]) < fraction
+        amp = rs.random_sample(vis.shape[1]) * 20.0 + 50.0
+        phase = rs.random_sample(vis.shape[1]) * (2j * np.pi)
+        out[i] = (out[i].astype(np.complex128) + s * (amp * np.exp(phase))).astype(np.complex64)
+    return out
+
+
+def config1():
+    """BASELINE.json config 1: generate_data(1024, 2048)."""
+    return generate_data(1024, 2048)
+
+
+def config1_rfi():
+    """Config 1 with injected RFI so that 'flags bit-identical' is not vacuous."""
+    return add_rfi(config1())
+
+
+def channel_mask(channels, seed=2, fraction=1.0 / 16.0):
+    """Per-channel input-flag mask of SURVEY 8(d) / config 5."""
+    return (np.random.RandomState(seed).random_sample(channels) < fraction).astype(np.uint8)
