@@ -56,6 +56,11 @@ def cpu_baseline(budget_s: float = 20.0):
     """
     from oracle import rfi_oracle as oracle
 
+    try:
+        cores_available = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores_available = os.cpu_count() or 1
+    threads = max(1, min(cores_available, oracle.max_threads(), 64))
     oracle.set_threads(1)
     baselines = 512
     vis = synth_block(CHANNELS, baselines, 1)
@@ -73,7 +78,6 @@ def cpu_baseline(budget_s: float = 20.0):
     samples = CHANNELS * baselines
     single = samples / dt
     # all cores, for context (OpenMP over baselines)
-    threads = min(os.cpu_count() or 1, oracle.max_threads(), 64)
     oracle.set_threads(threads)
     t0 = time.perf_counter()
     oracle.flagger_full(vis, width=WIDTH, n_sigma=N_SIGMA)

@@ -308,24 +308,27 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
                     const bool valid = (c0 + j + w <= C);
                     if (valid && s > limit) hits |= 1ull << j;
                 }
-                // dilation: a hit at j flags j..j+w-1; bring in up to 7 positions
-                // from the lanes below
-                unsigned long long comb = hits << 7;
+                // dilation: a hit at j flags j..j+w-1. `pin` holds the hits of the 7
+                // positions just below this lane's run (bit i <-> position i - 7).
+                unsigned pin = 0;
                 if (R >= 7) {
                     const unsigned long long prev = __shfl_up(hits, 1, 64);
-                    if (lane > 0) comb |= (prev >> (R - 7)) & 0x7full;
+                    if (lane > 0) pin = (unsigned)(prev >> (R - 7)) & 0x7fu;
                 } else {
 #pragma unroll
                     for (int back = 1; back * R < 7 + R; back++) {
                         const unsigned long long prev = __shfl_up(hits, back, 64);
                         const int sh = 7 - back * R;
-                        if (lane >= back) comb |= (sh >= 0 ? (prev << sh) : (prev >> (-sh))) & 0x7full;
+                        if (lane >= back)
+                            pin |= (unsigned)(sh >= 0 ? (prev << sh) : (prev >> (-sh))) & 0x7fu;
                     }
                 }
-                if (w >= 2) comb |= comb << 1;
-                if (w >= 4) comb |= comb << 2;
-                if (w >= 8) comb |= comb << 4;
-                fl |= (comb >> 7) & (R == 64 ? ~0ull : ((1ull << R) - 1));
+                unsigned long long own = hits;
+                if (w >= 2) { own |= own << 1; pin |= pin << 1; }
+                if (w >= 4) { own |= own << 2; pin |= pin << 2; }
+                if (w >= 8) { own |= own << 4; pin |= pin << 4; }
+                const unsigned long long comb = own | (unsigned long long)(pin >> 7);
+                fl |= comb & (R == 64 ? ~0ull : ((1ull << R) - 1));
             }
         }
     }

@@ -43,7 +43,7 @@ __device__ __forceinline__ float ksp_abs_c64(float re, float im)
     float mn = fminf(ar, ai);
     float r = __fdiv_rn(mn, mx);
     float t = __fmaf_rn(r, r, 1.0f);
-    float a = __fmul_rn(mx, __fsqrt_rn(t));
+    float a = __fmul_rn(mx, __builtin_sqrtf(t));
     if (mx == 0.0f) a = 0.0f;
     if (ar != ar || ai != ai) a = __builtin_nanf("");
     if (mx == __builtin_inff()) a = mx;

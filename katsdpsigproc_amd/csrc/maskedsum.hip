@@ -32,7 +32,7 @@ __global__ __launch_bounds__(MS_COLS *MS_PHASES) void maskedsum_kernel(
             const float m = mask[row];
             if (USE_AMP) {
                 // reference: fma(mask, sqrt(x*x + y*y), acc)  (maskedsum.mako:60)
-                const float a = __fsqrt_rn(__fadd_rn(__fmul_rn(c.x, c.x), __fmul_rn(c.y, c.y)));
+                const float a = __builtin_sqrtf(__fadd_rn(__fmul_rn(c.x, c.x), __fmul_rn(c.y, c.y)));
                 acc.x = __fmaf_rn(m, a, acc.x);
             } else {
                 acc.x = __fmaf_rn(m, c.x, acc.x);
