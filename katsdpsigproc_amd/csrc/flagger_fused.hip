@@ -29,6 +29,8 @@
 //     on one XCD so that their partial lines merge in that XCD's L2.
 //
 // Roofline: HBM, 9 algorithmic bytes per sample (8 read + 1 written).
+#include <stdlib.h>
+
 #include "median_window.h"
 
 #define FUSED_THREADS 512
@@ -45,6 +47,7 @@ struct FusedParams {
     int vis_stride, in_flags_stride, flags_stride, dev_stride;
     int is_amplitude, flags_mode, threshold_kind, n_windows, flag_value;
     int n_strips;
+    int debug_stop;  // diagnostic only (env KSP_FUSED_DEBUG_STOP): 0 = run everything
     double n_sigma;
     double scales[KSP_MAX_WINDOWS];
 };
@@ -60,6 +63,48 @@ struct FusedLayout {
 __device__ __forceinline__ double shfl_down_f64(double v, int delta)
 {
     return __shfl_down(v, delta, 64);
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Monotone 15-bit key of a non-negative double: float32-style exponent (8 bits) and
+// the top 7 mantissa bits, clamped. Zero maps to key 0.
+__device__ __forceinline__ unsigned key16_of(double a)
+{
+    const int hi = __double2hiint(a);
+    int k = (hi >> 13) - (896 << 7);  // rebias 11-bit exponent to 8 bits
+    k = min(max(k, 0), 32767);
+    return (unsigned)k;
+}
+
+// Wave-wide sum of a small per-lane count (< 2^BITS) without touching LDS: one
+// ballot + scalar popcount per bit.
+template <int BITS>
+__device__ __forceinline__ int wave_sum_small(int c)
+{
+    int total = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; b++)
+        total += __popcll(__ballot((c >> b) & 1)) << b;
+    return total;
+}
+
+// Number of keys (over the whole wave) strictly below T, 1 <= T <= 32768. Two keys
+// per register: (key - T) has bit 15 set exactly when key < T because both are below
+// 2^15, so three packed 16-bit operations handle two samples.
+template <int R>
+__device__ __forceinline__ int count_less16(const unsigned (&kp)[R / 2], unsigned T)
+{
+    const unsigned short t = (unsigned short)T;
+    const u16x2 tt = {t, t};
+    u16x2 acc = {0, 0};
+#pragma unroll
+    for (int i = 0; i < R / 2; i++) {
+        const u16x2 d = __builtin_bit_cast(u16x2, kp[i]) - tt;
+        acc += d >> (unsigned short)15;
+    }
+    const int c = (int)acc.x + (int)acc.y;
+    return wave_sum_small<8>(c);
 }
 
 template <int R, int WIDTH>
@@ -86,45 +131,64 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     const int b0 = strip * FUSED_STRIP;
 
     // ---- LOAD: vis -> amplitude -> LDS [baseline][channel] -----------------------
+    // Each lane owns a pair of baselines (16 B of a 64-byte row segment) and every
+    // 128th row. Loads are issued in batches of LB rows before any is consumed, so a
+    // CU keeps 512 x LB x 16 B in flight.
     {
-        const int q = tid & 3;         // which pair of baselines
-        const int r0 = tid >> 2;       // row within a pass of 128 rows
+        constexpr int LB = 8;
+        constexpr int RSTEP = FUSED_THREADS / 4;  // rows covered per pass
+        const int q = tid & 3;    // which pair of baselines
+        const int r0 = tid >> 2;  // row within a pass of 128 rows
         const int bl = b0 + 2 * q;
         const bool ok0 = bl < p.baselines, ok1 = bl + 1 < p.baselines;
-        for (int row = r0; row < C; row += FUSED_THREADS / 4) {
-            float a0 = __builtin_nanf(""), a1 = __builtin_nanf("");
-            if (p.is_amplitude) {
-                const float *src = (const float *)p.vis + (size_t)row * p.vis_stride + bl;
-                if (ok1) {
-                    const float2 v = *(const float2 *)src;
-                    a0 = v.x;
-                    a1 = v.y;
-                } else if (ok0)
-                    a0 = src[0];
-            } else {
-                const float2 *src = (const float2 *)p.vis + (size_t)row * p.vis_stride + bl;
-                if (ok1) {
-                    const float4 v = *(const float4 *)src;
-                    a0 = ksp_abs_c64(v.x, v.y);
-                    a1 = ksp_abs_c64(v.z, v.w);
-                } else if (ok0) {
-                    const float2 v = src[0];
-                    a0 = ksp_abs_c64(v.x, v.y);
+        const bool plain = !p.is_amplitude && ok1;  // the common, fully vectorised case
+        for (int rbase = r0; rbase < C; rbase += RSTEP * LB) {
+            float4 raw[LB];
+            if (plain) {
+#pragma unroll
+                for (int u = 0; u < LB; u++) {
+                    const int row = rbase + u * RSTEP;
+                    raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < C)
+                        raw[u] = *(const float4 *)((const float2 *)p.vis +
+                                                   (size_t)row * p.vis_stride + bl);
                 }
             }
-            if (p.flags_mode == KSP_FLAGS_CHANNEL) {
-                if (p.in_flags[row]) a0 = a1 = __builtin_nanf("");
-            } else if (p.flags_mode == KSP_FLAGS_FULL) {
-                const uint8_t *f = p.in_flags + (size_t)row * p.in_flags_stride + bl;
-                if (ok0 && f[0]) a0 = __builtin_nanf("");
-                if (ok1 && f[1]) a1 = __builtin_nanf("");
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int row = rbase + u * RSTEP;
+                if (row >= C) break;
+                float a0 = __builtin_nanf(""), a1 = __builtin_nanf("");
+                if (plain) {
+                    a0 = ksp_abs_c64(raw[u].x, raw[u].y);
+                    a1 = ksp_abs_c64(raw[u].z, raw[u].w);
+                } else if (p.is_amplitude) {
+                    const float *src = (const float *)p.vis + (size_t)row * p.vis_stride + bl;
+                    if (ok1) {
+                        const float2 v = *(const float2 *)src;
+                        a0 = v.x;
+                        a1 = v.y;
+                    } else if (ok0)
+                        a0 = src[0];
+                } else if (ok0) {
+                    const float2 v = ((const float2 *)p.vis)[(size_t)row * p.vis_stride + bl];
+                    a0 = ksp_abs_c64(v.x, v.y);
+                }
+                if (p.flags_mode == KSP_FLAGS_CHANNEL) {
+                    if (p.in_flags[row]) a0 = a1 = __builtin_nanf("");
+                } else if (p.flags_mode == KSP_FLAGS_FULL) {
+                    const uint8_t *f = p.in_flags + (size_t)row * p.in_flags_stride + bl;
+                    if (ok0 && f[0]) a0 = __builtin_nanf("");
+                    if (ok1 && f[1]) a1 = __builtin_nanf("");
+                }
+                const int idx = LY::index(row);
+                lds[(2 * q) * LY::ROW + idx] = a0;
+                lds[(2 * q + 1) * LY::ROW + idx] = a1;
             }
-            const int idx = LY::index(row);
-            lds[(2 * q) * LY::ROW + idx] = a0;
-            lds[(2 * q + 1) * LY::ROW + idx] = a1;
         }
     }
     __syncthreads();
+    if (p.debug_stop == 1) return;
 
     // ---- per-baseline, wave-local part --------------------------------------------
     const int bl = b0 + wave;
@@ -137,6 +201,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     // |deviation| in float64 registers, signs in a bit mask: the MAD search can then
     // order samples by the high word of the IEEE pattern without a separate key array.
     double adev[R];
+    unsigned kp[R / 2];              // 16-bit selection keys, two per register (see MAD)
     unsigned long long neg = 0;      // bit j: deviation of channel c0 + j is negative
     double dmax = -__builtin_inf();  // largest signed deviation of this lane
     {
@@ -165,20 +230,29 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
             dmax = fmax(dmax, d);
             if (d < 0.0) neg |= 1ull << j;
             adev[j] = fabs(d);
+            const unsigned k16 = key16_of(adev[j]);
+            if (j & 1)
+                kp[j / 2] |= k16 << 16;
+            else
+                kp[j / 2] = k16;
         }
     }
     auto signed_dev = [&](int j) -> double { return ((neg >> j) & 1) ? -adev[j] : adev[j]; };
-
-    // ---- optional deviations output: stage float32 in this wave's LDS row ---------
-    if (p.deviations != nullptr) {
+    if (p.debug_stop == 2) {
+        double acc = dmax;
 #pragma unroll
-        for (int j = 0; j < R; j++) myrow[lane * LY::RUN + j] = (float)signed_dev(j);
+        for (int j = 0; j < R; j++) acc += adev[j];
+        if (acc == 12345.678 && p.noise) p.noise[0] = (float)neg;  // keep the work alive
+        return;
     }
 
     // ---- MAD: median of non-zero |dev| -------------------------------------------
-    // Selection runs on the high 32 bits of the float64 pattern of |dev| (monotone
-    // in |dev|), then the exact value is resolved among the samples that share the
-    // selected high word (normally exactly one).
+    // 1. 15-pass bit-wise search on packed 16-bit keys finds the key bin K that holds
+    //    the median and the number of samples below the bin;
+    // 2. the (few) samples of bin K are copied to this wave's LDS row and ranked
+    //    exactly in float64;
+    // 3. degenerate data (hundreds of samples in one bin) falls back to an exact
+    //    search on the float64 bit patterns.
     double noise64;
     {
         int zeros = 0;
@@ -191,71 +265,149 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         } else {
             const int rank2 = total + zeros;
             const int rank = rank2 / 2;  // rank of the (upper) median among all slots
-            unsigned cur = 0;
-            for (int bit = 30; bit >= 0; bit--) {
-                const unsigned test = cur | (1u << bit);
-                int c = 0;
-#pragma unroll
-                for (int j = 0; j < R; j++) c += (unsigned)__double2hiint(adev[j]) < test;
-                c = ksp_wave_sum(c);
-                if (c <= rank) cur = test;
-            }
-            int less = 0, ties = 0;
-            double tmin = __builtin_inf(), tmax = 0.0;
-#pragma unroll
-            for (int j = 0; j < R; j++) {
-                const unsigned hi = (unsigned)__double2hiint(adev[j]);
-                less += hi < cur;
-                ties += hi == cur;
-                tmin = hi == cur ? fmin(tmin, adev[j]) : tmin;
-                tmax = hi == cur ? fmax(tmax, adev[j]) : tmax;
-            }
-            less = ksp_wave_sum(less);
-            ties = ksp_wave_sum(ties);
-            tmin = ksp_wave_min(tmin);
-            tmax = ksp_wave_max(tmax);
-            double xk = tmin;
-            if (tmin != tmax) {
-                // several distinct values share the high word: walk them in order
-                int r = rank - less;  // 0-based rank inside the tie set
-                double curv = -1.0;
-                for (int it = 0; it < ties; it++) {
-                    double nxt = __builtin_inf();
-#pragma unroll
-                    for (int j = 0; j < R; j++) {
-                        const bool tie = (unsigned)__double2hiint(adev[j]) == cur;
-                        if (tie && adev[j] > curv) nxt = fmin(nxt, adev[j]);
-                    }
-                    nxt = ksp_wave_min(nxt);
-                    int cnt = 0;
-#pragma unroll
-                    for (int j = 0; j < R; j++) cnt += (adev[j] == nxt);
-                    cnt = ksp_wave_sum(cnt);
-                    xk = nxt;
-                    if (r < cnt) break;
-                    r -= cnt;
-                    curv = nxt;
+            const bool even = !(rank2 & 1);
+            unsigned K = 0;
+            int below_bin = 0;
+            for (int bit = 14; bit >= 0; bit--) {
+                const unsigned test = K | (1u << bit);
+                const int c = count_less16<R>(kp, test);
+                if (c <= rank) {
+                    K = test;
+                    below_bin = c;
                 }
             }
-            if (!(rank2 & 1)) {
-                // even count: mean with the next value down (float64, as numpy.median)
-                int c = 0;
-                double below = 0.0;
+            const int in_bin = count_less16<R>(kp, K + 1) - below_bin;
+            const int r = rank - below_bin;  // 0-based rank inside the bin
+            double xk, prev;
+            bool have_prev = false;
+            constexpr int MAX_LIST = 512;
+            if (in_bin <= MAX_LIST) {
+                // gather the bin into LDS (this wave's row is free: amplitudes are consumed)
+                double *list = (double *)myrow;
+                int base = 0;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    const bool lt = adev[j] < xk;
-                    c += lt;
-                    below = lt ? fmax(below, adev[j]) : below;
+                    const unsigned k16 = (j & 1) ? (kp[j / 2] >> 16) : (kp[j / 2] & 0xffffu);
+                    const bool is = (k16 == K);
+                    const unsigned long long m = __ballot(is);
+                    if (m) {  // wave-uniform, rarely taken
+                        const int pos = base + __builtin_amdgcn_mbcnt_hi(
+                                                   (unsigned)(m >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        if (is) list[pos] = adev[j];
+                        base += __popcll(m);
+                    }
                 }
-                c = ksp_wave_sum(c);
-                below = ksp_wave_max(below);
-                const double prev = (c == rank) ? below : xk;
-                xk = (xk + prev) / 2.0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // exact stable rank of every listed value; rank r is the upper median
+                xk = 0.0;
+                prev = 0.0;
+                for (int ci = lane; ci < ((in_bin + 63) & ~63); ci += 64) {
+                    const bool live = ci < in_bin;
+                    const double x = live ? list[ci] : 0.0;
+                    int cnt = 0;
+                    for (int jj = 0; jj < in_bin; jj++) {
+                        const double y = list[jj];
+                        cnt += (y < x) || (y == x && jj < ci);
+                    }
+                    const unsigned long long hit = __ballot(live && cnt == r);
+                    const unsigned long long hitp = __ballot(live && cnt == r - 1);
+                    if (hit) xk = __shfl(x, __ffsll((long long)hit) - 1, 64);
+                    if (hitp) {
+                        prev = __shfl(x, __ffsll((long long)hitp) - 1, 64);
+                        have_prev = true;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (even && !have_prev) {
+                    // r == 0: the lower median is the largest value below the bin
+                    double below = 0.0;
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        const unsigned k16 = (j & 1) ? (kp[j / 2] >> 16) : (kp[j / 2] & 0xffffu);
+                        below = (k16 < K) ? fmax(below, adev[j]) : below;
+                    }
+                    prev = ksp_wave_max(below);
+                }
+                if (even) xk = (xk + prev) / 2.0;  // float64 mean, as numpy.median
+            } else {
+                // exact search on the high words of the float64 patterns (slow, rare)
+                unsigned cur = 0;
+                for (int bit = 30; bit >= 0; bit--) {
+                    const unsigned test = cur | (1u << bit);
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < R; j++) c += (unsigned)__double2hiint(adev[j]) < test;
+                    c = ksp_wave_sum(c);
+                    if (c <= rank) cur = test;
+                }
+                int less = 0, ties = 0;
+                double tmin = __builtin_inf(), tmax = 0.0;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const unsigned hi = (unsigned)__double2hiint(adev[j]);
+                    less += hi < cur;
+                    ties += hi == cur;
+                    tmin = hi == cur ? fmin(tmin, adev[j]) : tmin;
+                    tmax = hi == cur ? fmax(tmax, adev[j]) : tmax;
+                }
+                less = ksp_wave_sum(less);
+                ties = ksp_wave_sum(ties);
+                tmin = ksp_wave_min(tmin);
+                tmax = ksp_wave_max(tmax);
+                xk = tmin;
+                if (tmin != tmax) {
+                    // several distinct values share the high word: walk them in order
+                    int rr = rank - less;  // 0-based rank inside the tie set
+                    double curv = -1.0;
+                    for (int it = 0; it < ties; it++) {
+                        double nxt = __builtin_inf();
+#pragma unroll
+                        for (int j = 0; j < R; j++) {
+                            const bool tie = (unsigned)__double2hiint(adev[j]) == cur;
+                            if (tie && adev[j] > curv) nxt = fmin(nxt, adev[j]);
+                        }
+                        nxt = ksp_wave_min(nxt);
+                        int cnt = 0;
+#pragma unroll
+                        for (int j = 0; j < R; j++) cnt += (adev[j] == nxt);
+                        cnt = ksp_wave_sum(cnt);
+                        xk = nxt;
+                        if (rr < cnt) break;
+                        rr -= cnt;
+                        curv = nxt;
+                    }
+                }
+                if (!(rank2 & 1)) {
+                    // even count: mean with the next value down (float64, as numpy.median)
+                    int c = 0;
+                    double below = 0.0;
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        const bool lt = adev[j] < xk;
+                        c += lt;
+                        below = lt ? fmax(below, adev[j]) : below;
+                    }
+                    c = ksp_wave_sum(c);
+                    below = ksp_wave_max(below);
+                    const double lower = (c == rank) ? below : xk;
+                    xk = (xk + lower) / 2.0;
+                }
             }
             noise64 = xk * FUSED_MAD_NORMAL;
         }
     }
     if (lane == 0 && p.noise != nullptr && bl < p.baselines) p.noise[bl] = (float)noise64;
+
+    // ---- optional deviations output: stage float32 in this wave's LDS row
+    // (after MAD, which borrows the row for its candidate list) ---------
+    if (p.deviations != nullptr) {
+#pragma unroll
+        for (int j = 0; j < R; j++) myrow[lane * LY::RUN + j] = (float)signed_dev(j);
+    }
+
+    if (p.debug_stop == 3) return;
 
     // ---- thresholds ----------------------------------------------------------------
     unsigned long long fl = 0;  // bit j: channel c0 + j flagged
@@ -334,8 +486,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     }
 
     // ---- outputs ---------------------------------------------------------------------
-    __syncthreads();  // every wave is done with the amplitude rows
+    if (p.debug_stop == 4) {
+        if (fl == 0x123456789abcull && p.noise) p.noise[0] = 1.0f;
+        return;
+    }
     if (p.deviations != nullptr) {
+        __syncthreads();  // every wave has staged its float32 deviations
         // rows now hold float32 deviations; write them as [channel][8 baselines]
         const int q = tid & 3, r0 = tid >> 2;
         const int blq = b0 + 2 * q;
@@ -353,27 +509,45 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         }
         __syncthreads();
     }
-    // flags: stage as bytes [channel][8] in LDS, then 8-byte row stores
-    uint8_t *fstage = (uint8_t *)lds;
-    {
-        const uint8_t fv = (uint8_t)p.flag_value;
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int c = c0 + j;
-            if (c < C) fstage[c * FUSED_STRIP + wave] = ((fl >> j) & 1) ? fv : 0;
-        }
-    }
-    __syncthreads();
+    // flags: rows of 8 bytes (one per baseline of the strip). Most blocks have no flag
+    // at all and store zeros straight from registers; otherwise the rows are built in
+    // LDS (zero fill, then one byte per flagged sample) and stored 8 bytes at a time.
     {
         const bool full = (b0 + FUSED_STRIP <= p.baselines) && ((p.flags_stride & 7) == 0) &&
                           (((uintptr_t)p.flags & 7) == 0);
+        unsigned *anyflag = (unsigned *)(lds + LY::LDS_FLOATS);  // 8 words past the rows
+        const unsigned wave_any = (__ballot(fl != 0) != 0);  // all lanes take part
+        if (lane == 0) anyflag[wave] = wave_any;
+        __syncthreads();
+        unsigned block_any = 0;
+#pragma unroll
+        for (int w = 0; w < FUSED_STRIP; w++) block_any |= anyflag[w];
+        uint8_t *fstage = (uint8_t *)lds;
+        if (block_any) {
+            __syncthreads();  // everyone has read anyflag (it sits past the stage, but keep order)
+            for (int i = tid; i < C * FUSED_STRIP / 8; i += FUSED_THREADS)
+                ((uint2 *)fstage)[i] = make_uint2(0u, 0u);
+            __syncthreads();
+            const uint8_t fv = (uint8_t)p.flag_value;
+            unsigned long long m = fl;
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int c = c0 + j;
+                if (c < C) fstage[c * FUSED_STRIP + wave] = fv;
+            }
+            __syncthreads();
+        }
         for (int row = tid; row < C; row += FUSED_THREADS) {
             uint8_t *dst = p.flags + (size_t)row * p.flags_stride + b0;
+            uint2 v = make_uint2(0u, 0u);
+            if (block_any) v = *(const uint2 *)(fstage + row * FUSED_STRIP);
             if (full)
-                *(uint2 *)dst = *(const uint2 *)(fstage + row * FUSED_STRIP);
-            else
-                for (int i = 0; i < FUSED_STRIP && b0 + i < p.baselines; i++)
-                    dst[i] = fstage[row * FUSED_STRIP + i];
+                *(uint2 *)dst = v;
+            else {
+                const uint8_t *vb = (const uint8_t *)&v;
+                for (int i = 0; i < FUSED_STRIP && b0 + i < p.baselines; i++) dst[i] = vb[i];
+            }
         }
     }
 }
@@ -382,9 +556,9 @@ template <int R, int WIDTH>
 static int launch_fused(hipStream_t s, const FusedParams &p)
 {
     using LY = FusedLayout<R>;
-    size_t lds_bytes = sizeof(float) * LY::LDS_FLOATS;
+    size_t lds_bytes = sizeof(float) * LY::LDS_FLOATS + 64;
     const size_t stage = (size_t)p.channels * FUSED_STRIP;
-    if (stage > lds_bytes) lds_bytes = stage;
+    if (stage + 64 > lds_bytes) lds_bytes = stage + 64;
     auto kern = flagger_fused_kernel<R, WIDTH>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -450,6 +624,10 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     p.n_windows = n_windows;
     p.flag_value = flag_value;
     p.n_strips = ksp_divup(baselines, FUSED_STRIP);
+    {
+        const char *dbg = getenv("KSP_FUSED_DEBUG_STOP");
+        p.debug_stop = dbg ? atoi(dbg) : 0;
+    }
     p.n_sigma = n_sigma;
     for (int k = 0; k < KSP_MAX_WINDOWS; k++)
         p.scales[k] = (scales64 != nullptr && k < n_windows) ? scales64[k] : 0.0;

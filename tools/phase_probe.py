@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: time the fused flagger with the kernel stopped after each phase
+(KSP_FUSED_DEBUG_STOP), to see where a strip spends its time. Not part of the product."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from katsdpsigproc_amd import accel  # noqa: E402
+from katsdpsigproc_amd.rfi import device  # noqa: E402
+
+channels = int(os.environ.get("CH", 4096))
+baselines = int(os.environ.get("BL", 32768))
+ctx = accel.create_some_context(False)
+q = ctx.create_command_queue()
+t = device.FlaggerDeviceTemplate(
+    device.BackgroundMedianFilterDeviceTemplate(ctx, 13),
+    device.NoiseEstMADTDeviceTemplate(ctx, 10240),
+    device.ThresholdSumDeviceTemplate(ctx), keep_deviations=False)
+fn = t.instantiate(q, channels, baselines, threshold_args={"n_sigma": 11.0})
+fn.ensure_all_bound()
+rs = np.random.RandomState(1)
+vis = (rs.standard_normal((channels, baselines)).astype(np.float32)
+       + 1j * rs.standard_normal((channels, baselines)).astype(np.float32)).astype(np.complex64)
+fn.buffer("vis").set(q, vis)
+names = {1: "load", 2: "+median", 3: "+mad", 4: "+threshold", 0: "full"}
+for stop in (1, 2, 3, 4, 0):
+    os.environ["KSP_FUSED_DEBUG_STOP"] = str(stop)
+    fn(); q.finish()
+    a = q.enqueue_marker()
+    for _ in range(5):
+        fn()
+    b = q.enqueue_marker()
+    q.finish()
+    print(f"stop={stop} {names[stop]:>12}: {1e3 * b.time_since(a) / 5:.3f} ms", flush=True)
