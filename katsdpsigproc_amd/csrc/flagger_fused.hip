@@ -89,22 +89,42 @@ __device__ __forceinline__ int wave_sum_small(int c)
     return total;
 }
 
+// Selection keys live in the wave's (by then dead) amplitude row in LDS, two 16-bit
+// keys per word, laid out so that lane l reads chunk t as one 16-byte access at
+// word (t * 64 + l) * 4: consecutive lanes, consecutive 16-byte slots, no conflicts.
+template <int R>
+struct KeyStore {
+    static constexpr int CHUNKS = (R / 2 + 3) / 4;       // 16-byte chunks per lane
+    static constexpr int WORDS = CHUNKS * 64 * 4;        // words used in the row
+    static constexpr int PER_CHUNK = (R / 2 >= 4) ? 4 : R / 2;  // packed words per chunk
+};
+
 // Number of keys (over the whole wave) strictly below T, 1 <= T <= 32768. Two keys
-// per register: (key - T) has bit 15 set exactly when key < T because both are below
+// per word: (key - T) has bit 15 set exactly when key < T because both are below
 // 2^15, so three packed 16-bit operations handle two samples.
 template <int R>
-__device__ __forceinline__ int count_less16(const unsigned (&kp)[R / 2], unsigned T)
+__device__ __forceinline__ int count_less16(const uint4 *keys, int lane, unsigned T)
 {
+    using KS = KeyStore<R>;
     const unsigned short t = (unsigned short)T;
     const u16x2 tt = {t, t};
-    u16x2 acc = {0, 0};
+    u16x2 acc0 = {0, 0}, acc1 = {0, 0};
 #pragma unroll
-    for (int i = 0; i < R / 2; i++) {
-        const u16x2 d = __builtin_bit_cast(u16x2, kp[i]) - tt;
-        acc += d >> (unsigned short)15;
+    for (int c = 0; c < KS::CHUNKS; c++) {
+        const uint4 kk = keys[c * 64 + lane];
+        const unsigned w[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+        for (int e = 0; e < KS::PER_CHUNK; e++) {
+            const u16x2 d = __builtin_bit_cast(u16x2, w[e]) - tt;
+            if (e & 1)
+                acc1 += d >> (unsigned short)15;
+            else
+                acc0 += d >> (unsigned short)15;
+        }
     }
-    const int c = (int)acc.x + (int)acc.y;
-    return wave_sum_small<8>(c);
+    const u16x2 acc = acc0 + acc1;
+    const int cnt = (int)acc.x + (int)acc.y;
+    return wave_sum_small<8>(cnt);
 }
 
 template <int R, int WIDTH>
@@ -135,7 +155,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     // 128th row. Loads are issued in batches of LB rows before any is consumed, so a
     // CU keeps 512 x LB x 16 B in flight.
     {
-        constexpr int LB = 8;
+        constexpr int LB = (R >= 32) ? R / 2 : 8;  // R=64: all 32 rows of a lane at once
         constexpr int RSTEP = FUSED_THREADS / 4;  // rows covered per pass
         const int q = tid & 3;    // which pair of baselines
         const int r0 = tid >> 2;  // row within a pass of 128 rows
@@ -201,7 +221,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     // |deviation| in float64 registers, signs in a bit mask: the MAD search can then
     // order samples by the high word of the IEEE pattern without a separate key array.
     double adev[R];
-    unsigned kp[R / 2];              // 16-bit selection keys, two per register (see MAD)
     unsigned long long neg = 0;      // bit j: deviation of channel c0 + j is negative
     double dmax = -__builtin_inf();  // largest signed deviation of this lane
     {
@@ -230,11 +249,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
             dmax = fmax(dmax, d);
             if (d < 0.0) neg |= 1ull << j;
             adev[j] = fabs(d);
-            const unsigned k16 = key16_of(adev[j]);
-            if (j & 1)
-                kp[j / 2] |= k16 << 16;
-            else
-                kp[j / 2] = k16;
         }
     }
     auto signed_dev = [&](int j) -> double { return ((neg >> j) & 1) ? -adev[j] : adev[j]; };
@@ -255,10 +269,24 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     //    search on the float64 bit patterns.
     double noise64;
     {
+        using KS = KeyStore<R>;
+        uint4 *keys = (uint4 *)myrow;  // the amplitude row is dead from here on
         int zeros = 0;
 #pragma unroll
-        for (int j = 0; j < R; j++) zeros += (adev[j] == 0.0);
-        zeros = ksp_wave_sum(zeros);
+        for (int c = 0; c < KS::CHUNKS; c++) {
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < KS::PER_CHUNK; e++) {
+                const int j = (c * 4 + e) * 2;
+                zeros += (adev[j] == 0.0) + (adev[j + 1] == 0.0);
+                w[e] = key16_of(adev[j]) | (key16_of(adev[j + 1]) << 16);
+            }
+            keys[c * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        zeros = wave_sum_small<8>(zeros);
+        if (p.debug_stop == 31) { if (zeros == -7 && p.noise) p.noise[0] = 1.f; return; }
         const int total = 64 * R;
         if (zeros == total) {
             noise64 = __builtin_nan("");  // numpy: median of nothing
@@ -270,66 +298,109 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
             int below_bin = 0;
             for (int bit = 14; bit >= 0; bit--) {
                 const unsigned test = K | (1u << bit);
-                const int c = count_less16<R>(kp, test);
+                const int c = count_less16<R>(keys, lane, test);
                 if (c <= rank) {
                     K = test;
                     below_bin = c;
                 }
             }
-            const int in_bin = count_less16<R>(kp, K + 1) - below_bin;
+            if (p.debug_stop == 32) { if (K == 99999u && p.noise) p.noise[0] = (float)below_bin; return; }
+            const int in_bin = count_less16<R>(keys, lane, K + 1) - below_bin;
             const int r = rank - below_bin;  // 0-based rank inside the bin
             double xk, prev;
             bool have_prev = false;
-            constexpr int MAX_LIST = 512;
+            // candidate list: float64, behind the keys in the same row
+            double *list = (double *)(myrow + KS::WORDS);
+            constexpr int LIST_CAP = (LY::ROW - KS::WORDS) / 2;
+            constexpr int MAX_LIST = LIST_CAP < 512 ? LIST_CAP : 512;
             if (in_bin <= MAX_LIST) {
-                // gather the bin into LDS (this wave's row is free: amplitudes are consumed)
-                double *list = (double *)myrow;
                 int base = 0;
 #pragma unroll
-                for (int j = 0; j < R; j++) {
-                    const unsigned k16 = (j & 1) ? (kp[j / 2] >> 16) : (kp[j / 2] & 0xffffu);
-                    const bool is = (k16 == K);
-                    const unsigned long long m = __ballot(is);
-                    if (m) {  // wave-uniform, rarely taken
-                        const int pos = base + __builtin_amdgcn_mbcnt_hi(
-                                                   (unsigned)(m >> 32),
-                                                   __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        if (is) list[pos] = adev[j];
-                        base += __popcll(m);
+                for (int c = 0; c < KS::CHUNKS; c++) {
+                    const uint4 kk = keys[c * 64 + lane];
+                    const unsigned w[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+                    for (int e = 0; e < KS::PER_CHUNK; e++) {
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int j = (c * 4 + e) * 2 + h;
+                            const unsigned k16 = h ? (w[e] >> 16) : (w[e] & 0xffffu);
+                            const bool is = (k16 == K);
+                            const unsigned long long m = __ballot(is);
+                            if (m) {  // wave-uniform, rarely taken
+                                const int pos = base + __builtin_amdgcn_mbcnt_hi(
+                                                           (unsigned)(m >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                                if (is) list[pos] = adev[j];
+                                base += __popcll(m);
+                            }
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                if (p.debug_stop == 33) { if (base == -7 && p.noise) p.noise[0] = (float)list[0]; return; }
                 // exact stable rank of every listed value; rank r is the upper median
                 xk = 0.0;
                 prev = 0.0;
-                for (int ci = lane; ci < ((in_bin + 63) & ~63); ci += 64) {
-                    const bool live = ci < in_bin;
-                    const double x = live ? list[ci] : 0.0;
+                if (in_bin <= 64) {
+                    // one candidate per lane; the others arrive by lane broadcast
+                    const bool live = lane < in_bin;
+                    const double x = live ? list[lane] : 0.0;
                     int cnt = 0;
+                    const int xlo = __double2loint(x), xhi = __double2hiint(x);
                     for (int jj = 0; jj < in_bin; jj++) {
-                        const double y = list[jj];
-                        cnt += (y < x) || (y == x && jj < ci);
+                        // uniform source lane: v_readlane_b32, no LDS round trip
+                        const double y = __hiloint2double(__builtin_amdgcn_readlane(xhi, jj),
+                                                          __builtin_amdgcn_readlane(xlo, jj));
+                        cnt += (y < x) || (y == x && jj < lane);
                     }
                     const unsigned long long hit = __ballot(live && cnt == r);
                     const unsigned long long hitp = __ballot(live && cnt == r - 1);
-                    if (hit) xk = __shfl(x, __ffsll((long long)hit) - 1, 64);
+                    xk = __shfl(x, __ffsll((long long)hit) - 1, 64);
                     if (hitp) {
                         prev = __shfl(x, __ffsll((long long)hitp) - 1, 64);
                         have_prev = true;
                     }
+                } else {
+                    for (int ci = lane; ci < ((in_bin + 63) & ~63); ci += 64) {
+                        const bool live = ci < in_bin;
+                        const double x = live ? list[ci] : 0.0;
+                        int cnt = 0;
+                        for (int jj = 0; jj < in_bin; jj++) {
+                            const double y = list[jj];
+                            cnt += (y < x) || (y == x && jj < ci);
+                        }
+                        const unsigned long long hit = __ballot(live && cnt == r);
+                        const unsigned long long hitp = __ballot(live && cnt == r - 1);
+                        if (hit) xk = __shfl(x, __ffsll((long long)hit) - 1, 64);
+                        if (hitp) {
+                            prev = __shfl(x, __ffsll((long long)hitp) - 1, 64);
+                            have_prev = true;
+                        }
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (p.debug_stop == 34) { if (xk == -7.0 && p.noise) p.noise[0] = (float)prev; return; }
                 if (even && !have_prev) {
                     // r == 0: the lower median is the largest value below the bin
+                    // (keys are re-read from LDS, not recomputed: keeping 64 keys
+                    // alive in registers across the search would spill)
                     double below = 0.0;
 #pragma unroll
-                    for (int j = 0; j < R; j++) {
-                        const unsigned k16 = (j & 1) ? (kp[j / 2] >> 16) : (kp[j / 2] & 0xffffu);
-                        below = (k16 < K) ? fmax(below, adev[j]) : below;
+                    for (int c = 0; c < KS::CHUNKS; c++) {
+                        const uint4 kk = keys[c * 64 + lane];
+                        const unsigned w[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+                        for (int e = 0; e < KS::PER_CHUNK; e++) {
+                            const int j = (c * 4 + e) * 2;
+                            below = ((w[e] & 0xffffu) < K) ? fmax(below, adev[j]) : below;
+                            below = ((w[e] >> 16) < K) ? fmax(below, adev[j + 1]) : below;
+                        }
                     }
                     prev = ksp_wave_max(below);
                 }
+                if (p.debug_stop == 35) { if (xk == -7.0 && p.noise) p.noise[0] = (float)prev; return; }
                 if (even) xk = (xk + prev) / 2.0;  // float64 mean, as numpy.median
             } else {
                 // exact search on the high words of the float64 patterns (slow, rare)
@@ -398,6 +469,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
             noise64 = xk * FUSED_MAD_NORMAL;
         }
     }
+    if (p.debug_stop == 36) { if (noise64 == -7.0 && p.noise) p.noise[0] = 1.f; return; }
     if (lane == 0 && p.noise != nullptr && bl < p.baselines) p.noise[bl] = (float)noise64;
 
     // ---- optional deviations output: stage float32 in this wave's LDS row
@@ -509,45 +581,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         }
         __syncthreads();
     }
-    // flags: rows of 8 bytes (one per baseline of the strip). Most blocks have no flag
-    // at all and store zeros straight from registers; otherwise the rows are built in
-    // LDS (zero fill, then one byte per flagged sample) and stored 8 bytes at a time.
-    {
-        const bool full = (b0 + FUSED_STRIP <= p.baselines) && ((p.flags_stride & 7) == 0) &&
-                          (((uintptr_t)p.flags & 7) == 0);
-        unsigned *anyflag = (unsigned *)(lds + LY::LDS_FLOATS);  // 8 words past the rows
-        const unsigned wave_any = (__ballot(fl != 0) != 0);  // all lanes take part
-        if (lane == 0) anyflag[wave] = wave_any;
-        __syncthreads();
-        unsigned block_any = 0;
-#pragma unroll
-        for (int w = 0; w < FUSED_STRIP; w++) block_any |= anyflag[w];
-        uint8_t *fstage = (uint8_t *)lds;
-        if (block_any) {
-            __syncthreads();  // everyone has read anyflag (it sits past the stage, but keep order)
-            for (int i = tid; i < C * FUSED_STRIP / 8; i += FUSED_THREADS)
-                ((uint2 *)fstage)[i] = make_uint2(0u, 0u);
-            __syncthreads();
-            const uint8_t fv = (uint8_t)p.flag_value;
-            unsigned long long m = fl;
-            while (m) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int c = c0 + j;
-                if (c < C) fstage[c * FUSED_STRIP + wave] = fv;
-            }
-            __syncthreads();
-        }
-        for (int row = tid; row < C; row += FUSED_THREADS) {
-            uint8_t *dst = p.flags + (size_t)row * p.flags_stride + b0;
-            uint2 v = make_uint2(0u, 0u);
-            if (block_any) v = *(const uint2 *)(fstage + row * FUSED_STRIP);
-            if (full)
-                *(uint2 *)dst = v;
-            else {
-                const uint8_t *vb = (const uint8_t *)&v;
-                for (int i = 0; i < FUSED_STRIP && b0 + i < p.baselines; i++) dst[i] = vb[i];
-            }
+    // flags: the launcher zero-fills the whole flags array with one coalesced memset
+    // before this kernel (same stream), so only flagged samples are written here, one
+    // byte each. A strip is 8 bytes wide, which no store pattern of a single
+    // workgroup can turn into full 64-byte lines; flags are rare, the memset is not.
+    if (bl < p.baselines) {
+        const uint8_t fv = (uint8_t)p.flag_value;
+        unsigned long long m = fl;
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int c = c0 + j;
+            if (c < C) p.flags[(size_t)c * p.flags_stride + bl] = fv;
         }
     }
 }
@@ -556,9 +601,7 @@ template <int R, int WIDTH>
 static int launch_fused(hipStream_t s, const FusedParams &p)
 {
     using LY = FusedLayout<R>;
-    size_t lds_bytes = sizeof(float) * LY::LDS_FLOATS + 64;
-    const size_t stage = (size_t)p.channels * FUSED_STRIP;
-    if (stage + 64 > lds_bytes) lds_bytes = stage + 64;
+    const size_t lds_bytes = sizeof(float) * LY::LDS_FLOATS;
     auto kern = flagger_fused_kernel<R, WIDTH>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -566,6 +609,9 @@ static int launch_fused(hipStream_t s, const FusedParams &p)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    // all flags start at zero; the kernel only writes the (rare) non-zero ones
+    KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
+                             s));
     hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
     KSP_LAUNCH_CHECK();
     return 0;
