@@ -386,6 +386,10 @@ class Dimension:
 
     ALIGN_BYTES = 128
 
+    @classmethod
+    def _is_power2(cls, value: int) -> bool:
+        return value > 0 and (value & (value - 1)) == 0
+
     def __init__(
         self,
         size: int,
@@ -397,7 +401,7 @@ class Dimension:
     ) -> None:
         if min_padded_size is None:
             min_padded_size = size if min_padded_round is None else roundup(size, min_padded_round)
-        if alignment <= 0 or alignment & (alignment - 1):
+        if not self._is_power2(alignment):
             raise ValueError("alignment is not a power of 2")
         if min_padded_size < size:
             raise ValueError("padded size is less than size")
@@ -468,7 +472,7 @@ class Dimension:
         if self.frozen:
             raise ValueError("cannot modify a frozen requirement")
         itemsize = np.dtype(dtype).itemsize
-        if itemsize > 0 and itemsize & (itemsize - 1) == 0:
+        if self._is_power2(itemsize):
             req = self._root()._req
             req["hint"] = max(req["hint"], self.ALIGN_BYTES // itemsize)
 

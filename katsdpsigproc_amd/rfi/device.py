@@ -190,12 +190,13 @@ class BackgroundMedianFilterDevice(AbstractBackgroundDevice):
         self.channels = channels
         self.baselines = baselines
         vis_type = np.float32 if template.is_amplitude else np.complex64
-        # one Dimension object shared by vis and deviations: equal strides
+        # one Dimension object shared by vis, deviations and full flags: equal strides,
+        # as in the reference (rfi/device.py:303-307)
         dims = (channels, accel.Dimension(baselines))
         self.slots["vis"] = accel.IOSlot(dims, vis_type)
         self.slots["deviations"] = accel.IOSlot(dims, np.float32)
         if template.use_flags == BackgroundFlags.FULL:
-            self.slots["flags"] = accel.IOSlot((channels, accel.Dimension(baselines)), np.uint8)
+            self.slots["flags"] = accel.IOSlot(dims, np.uint8)
         elif template.use_flags == BackgroundFlags.CHANNEL:
             self.slots["flags"] = accel.IOSlot((channels,), np.uint8)
 
