@@ -1,0 +1,633 @@
+// Building blocks shared by the fused flagger kernels (flagger_fused.hip):
+// strip layout in LDS, cooperative strip load, the wave-local median / MAD /
+// threshold phases, flag output. See DESIGN.md section 4.1 for the reasoning.
+#pragma once
+#include <stdlib.h>
+
+#include "median_window.h"
+
+#define FUSED_THREADS 512
+#define FUSED_STRIP 8
+#define FUSED_MAD_NORMAL 1.4826
+
+struct FusedParams {
+    const void *vis;
+    const uint8_t *in_flags;
+    uint8_t *flags;
+    float *deviations;
+    float *noise;
+    int channels, baselines;
+    int vis_stride, in_flags_stride, flags_stride, dev_stride;
+    int is_amplitude, flags_mode, threshold_kind, n_windows, flag_value;
+    int n_strips;
+    int debug_stop;  // diagnostic only (env KSP_FUSED_DEBUG_STOP): 0 = run everything
+    double n_sigma;
+    double scales[KSP_MAX_WINDOWS];
+};
+
+// LDS image of one strip: 8 rows (one per baseline) of float32 amplitudes. Lane l of
+// the owning wavefront works on channels [l*R, (l+1)*R); its run is padded by 4 words
+// so that 16-byte reads of consecutive lanes fall in consecutive 16-byte slots, and
+// rows are offset by 8 words so that the 8 baselines written by one lane group hit
+// different banks. After the rows: one candidate list per wavefront for the MAD.
+template <int R>
+struct FusedLayout {
+    static constexpr int RUN = R + 4;
+    static constexpr int ROW = 64 * RUN + 8;
+    static constexpr int LDS_FLOATS = FUSED_STRIP * ROW;
+    static constexpr int LIST_DOUBLES = 256;  // per wavefront
+    static constexpr size_t LDS_BYTES =
+        sizeof(float) * LDS_FLOATS + sizeof(double) * LIST_DOUBLES * FUSED_STRIP;
+    __device__ static __forceinline__ int index(int c) { return (c / R) * RUN + (c % R); }
+};
+
+// blockIdx -> strip, XCD-aware: workgroups b, b+8, ... share an XCD, so the 8 strips
+// that make up one 512-byte input line / 64-byte output line are given to workgroups
+// of one XCD. Speed only -- any bijection is correct.
+__device__ __forceinline__ int strip_of(int id, int n_strips)
+{
+    const int full = (n_strips / 64) * 64;
+    if (id >= full) return id;
+    const int xcd = id & 7, i = id >> 3;
+    return ((i >> 3) * 8 + xcd) * 8 + (i & 7);
+}
+
+__device__ __forceinline__ float amp_with_flags(const FusedParams &p, float re, float im,
+                                                int row, int bl)
+{
+    float a = ksp_abs_c64(re, im);
+    if (p.flags_mode == KSP_FLAGS_CHANNEL) {
+        if (p.in_flags[row]) a = __builtin_nanf("");
+    } else if (p.flags_mode == KSP_FLAGS_FULL) {
+        if (p.in_flags[(size_t)row * p.in_flags_stride + bl]) a = __builtin_nanf("");
+    }
+    return a;
+}
+
+// Cooperative load of a whole strip: vis -> amplitude -> LDS rows. Each lane owns a
+// pair of baselines (16 B of the 64-byte row segment) and every 128th row; LB rows
+// are requested before the first is consumed.
+template <int R>
+__device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int b0, int tid)
+{
+    using LY = FusedLayout<R>;
+    constexpr int LB = (R >= 32) ? R / 2 : 8;
+    constexpr int RSTEP = FUSED_THREADS / 4;
+    const int C = p.channels;
+    const int q = tid & 3;
+    const int r0 = tid >> 2;
+    const int bl = b0 + 2 * q;
+    const bool ok0 = bl < p.baselines, ok1 = bl + 1 < p.baselines;
+    const bool plain = !p.is_amplitude && ok1;
+    for (int rbase = r0; rbase < C; rbase += RSTEP * LB) {
+        float4 raw[LB];
+        if (plain) {
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                const int row = rbase + u * RSTEP;
+                raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < C)
+                    raw[u] = *(const float4 *)((const float2 *)p.vis + (size_t)row * p.vis_stride + bl);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LB; u++) {
+            const int row = rbase + u * RSTEP;
+            if (row >= C) break;
+            float a0 = __builtin_nanf(""), a1 = __builtin_nanf("");
+            if (plain) {
+                a0 = amp_with_flags(p, raw[u].x, raw[u].y, row, bl);
+                a1 = amp_with_flags(p, raw[u].z, raw[u].w, row, bl + 1);
+            } else if (p.is_amplitude) {
+                const float *src = (const float *)p.vis + (size_t)row * p.vis_stride + bl;
+                if (ok0) a0 = src[0];
+                if (ok1) a1 = src[1];
+                if (p.flags_mode == KSP_FLAGS_CHANNEL) {
+                    if (p.in_flags[row]) a0 = a1 = __builtin_nanf("");
+                } else if (p.flags_mode == KSP_FLAGS_FULL) {
+                    const uint8_t *f = p.in_flags + (size_t)row * p.in_flags_stride + bl;
+                    if (ok0 && f[0]) a0 = __builtin_nanf("");
+                    if (ok1 && f[1]) a1 = __builtin_nanf("");
+                }
+            } else if (ok0) {
+                const float2 v = ((const float2 *)p.vis)[(size_t)row * p.vis_stride + bl];
+                a0 = amp_with_flags(p, v.x, v.y, row, bl);
+            }
+            const int idx = LY::index(row);
+            lds[(2 * q) * LY::ROW + idx] = a0;
+            lds[(2 * q + 1) * LY::ROW + idx] = a1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Median phase: lane l slides the sorted window over its run of R channels of the
+// wavefront's baseline. The deviation of every channel is computed in float64 (host
+// numerics) and kept ROUNDED TO FLOAT32 in registers -- 64 registers per lane instead
+// of 128 -- together with the exact largest deviation. Rounding is monotone, so order
+// statistics can be located on the float32 values; the few samples whose exact value
+// decides a result are recomputed in float64 on demand (exact_dev below).
+// `per_step(j)` is called once per output channel and lets the pipelined kernel
+// interleave the next strip's loads.
+template <int R, int WIDTH, class PerStep>
+__device__ __forceinline__ void median_phase(const float *myrow, int lane, int C, float (&dev)[R],
+                                             double &dmax, PerStep &&per_step)
+{
+    using LY = FusedLayout<R>;
+    constexpr int H = WIDTH / 2;
+    const int c0 = lane * R;
+    auto amp_at = [&](int c) -> float {
+        return (c >= 0 && c < C) ? myrow[LY::index(c)] : __builtin_nanf("");
+    };
+    dmax = -__builtin_inf();
+    MedianWindow<WIDTH> win;
+    win.reset();
+    float ring[WIDTH];
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) ring[i] = __builtin_nanf("");
+    // warm-up: samples c0-H .. c0+H-1 (ring slots 0 .. 2H-1)
+#pragma unroll
+    for (int k = 0; k < 2 * H; k++) {
+        const float a = amp_at(c0 - H + k);
+        win.step(ring[k % WIDTH], a);
+        ring[k % WIDTH] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        per_step(j);
+        const int k = 2 * H + j;  // step number; the entering sample is channel c0 + H + j
+        const float a = (j + H < R) ? myrow[lane * LY::RUN + j + H] : amp_at(c0 + H + j);
+        const float a_in = (c0 + H + j < C) ? a : __builtin_nanf("");
+        win.step(ring[k % WIDTH], a_in);
+        ring[k % WIDTH] = a_in;
+        const float xc = ring[(k + WIDTH - H) % WIDTH];  // centre sample: channel c0 + j
+        double d = 0.0;
+        if (xc == xc) d = (double)xc - win.median();
+        dmax = fmax(dmax, d);
+        dev[j] = (float)d;
+    }
+}
+
+// Exact float64 deviation of channel c, recomputed from the amplitudes of its window
+// (fetch(c) returns the float32 amplitude, NaN if the sample is masked or outside the
+// band). Same arithmetic as MedianWindow::median(): median of the valid samples, even
+// counts averaged in float64. Used only for the handful of samples that decide a
+// result, so it favours simplicity: invalid -> +inf, odd-even transposition sort.
+template <int WIDTH, class Fetch>
+__device__ __forceinline__ double exact_dev(int c, Fetch &&fetch)
+{
+    constexpr int H = WIDTH / 2;
+    float v[WIDTH];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < WIDTH; k++) {
+        const float a = fetch(c - H + k);
+        const bool ok = a == a;
+        n += ok;
+        v[k] = ok ? a : __builtin_inff();
+    }
+    const float centre = fetch(c);
+#pragma unroll
+    for (int round = 0; round < WIDTH; round++) {
+#pragma unroll
+        for (int i = round & 1; i + 1 < WIDTH; i += 2) {
+            const float lo = fminf(v[i], v[i + 1]), hi = fmaxf(v[i], v[i + 1]);
+            v[i] = lo;
+            v[i + 1] = hi;
+        }
+    }
+    float lo = v[0], hi = v[0];
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) {
+        lo = (i == ((n - 1) >> 1)) ? v[i] : lo;
+        hi = (i == (n >> 1)) ? v[i] : hi;
+    }
+    if (!(centre == centre) || n == 0) return 0.0;
+    const double med = (n & 1) ? (double)hi : ((double)lo + (double)hi) * 0.5;
+    return (double)centre - med;
+}
+
+// ---------------------------------------------------------------------------------
+// MAD: 1.4826 * median of the non-zero |deviations| of one baseline (whole wavefront).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Wave-wide sum of a small per-lane count (< 2^BITS) without touching LDS: one
+// ballot + scalar popcount per bit.
+template <int BITS>
+__device__ __forceinline__ int wave_sum_small(int c)
+{
+    int total = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; b++) total += __popcll(__ballot((c >> b) & 1)) << b;
+    return total;
+}
+
+__device__ __forceinline__ int wave_max_int(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Number of keys (over the whole wavefront) strictly below T, 1 <= T <= 32768. Two keys
+// per register: (key - T) has bit 15 set exactly when key < T because both are below
+// 2^15, so three packed 16-bit operations handle two samples.
+template <int NP>
+__device__ __forceinline__ int count_less16(const unsigned (&kp)[NP], unsigned T)
+{
+    const unsigned short t = (unsigned short)T;
+    const u16x2 tt = {t, t};
+    u16x2 acc0 = {0, 0}, acc1 = {0, 0};
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const u16x2 d = __builtin_bit_cast(u16x2, kp[i]) - tt;
+        if (i & 1)
+            acc1 += d >> (unsigned short)15;
+        else
+            acc0 += d >> (unsigned short)15;
+    }
+    const u16x2 acc = acc0 + acc1;
+    return wave_sum_small<8>((int)acc.x + (int)acc.y);
+}
+
+// Append the exact |deviation| of every sample whose bit is set in `cand` (bit j <->
+// channel c0 + j of this lane) to `list`, at most `cap` entries; returns the new
+// length (wave-uniform). All lanes stay active so that ballots see every lane.
+template <int WIDTH, class Fetch>
+__device__ __forceinline__ int gather_exact(unsigned long long cand, int c0, double *list,
+                                            int base, int cap, Fetch &&fetch)
+{
+    while (__any(cand != 0)) {
+        const bool has = cand != 0;
+        const int j = has ? __ffsll((long long)cand) - 1 : 0;
+        cand &= cand - 1;
+        const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
+        const unsigned long long m = __ballot(has);
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (has && pos < cap) list[pos] = x;
+        base += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return base;
+}
+
+// Values of (stable) rank r and r - 1 among list[0..n): each lane ranks the entries
+// ci = lane, lane + 64, ... against all others.
+__device__ __forceinline__ void rank_in_list(const double *list, int n, int r, int lane,
+                                             double &xk, double &prev, bool &have_prev)
+{
+    xk = 0.0;
+    prev = 0.0;
+    have_prev = false;
+    if (n <= 64) {
+        // one candidate per lane; the others arrive by lane broadcast (v_readlane)
+        const bool live = lane < n;
+        const double x = live ? list[lane] : 0.0;
+        const int xlo = __double2loint(x), xhi = __double2hiint(x);
+        int cnt = 0;
+        for (int jj = 0; jj < n; jj++) {
+            const double y = __hiloint2double(__builtin_amdgcn_readlane(xhi, jj),
+                                              __builtin_amdgcn_readlane(xlo, jj));
+            cnt += (y < x) || (y == x && jj < lane);
+        }
+        const unsigned long long hit = __ballot(live && cnt == r);
+        const unsigned long long hitp = __ballot(live && cnt == r - 1);
+        xk = __shfl(x, __ffsll((long long)hit) - 1, 64);
+        if (hitp) {
+            prev = __shfl(x, __ffsll((long long)hitp) - 1, 64);
+            have_prev = true;
+        }
+        return;
+    }
+    for (int ci = lane; ci < ((n + 63) & ~63); ci += 64) {
+        const bool live = ci < n;
+        const double x = live ? list[ci] : 0.0;
+        int cnt = 0;
+        for (int jj = 0; jj < n; jj++) {
+            const double y = list[jj];
+            cnt += (y < x) || (y == x && jj < ci);
+        }
+        const unsigned long long hit = __ballot(live && cnt == r);
+        const unsigned long long hitp = __ballot(live && cnt == r - 1);
+        if (hit) xk = __shfl(x, __ffsll((long long)hit) - 1, 64);
+        if (hitp) {
+            prev = __shfl(x, __ffsll((long long)hitp) - 1, 64);
+            have_prev = true;
+        }
+    }
+}
+
+// `list` is this wavefront's private candidate list in LDS (LIST_CAP doubles).
+// Returns the float64 noise estimate (NaN when every deviation is zero).
+template <int R, int WIDTH, int LIST_CAP, class Fetch>
+__device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, double *list,
+                                            Fetch &&fetch)
+{
+    constexpr int NP = R / 2;
+    const int c0 = lane * R;
+    // 1. 15-bit keys = float32 exponent + 7 mantissa bits of |dev|, two per register.
+    //    float32(|d|) is monotone in |d| and so is its truncation, hence the key bin of
+    //    the median can be found without knowing any exact value.
+    unsigned kp[NP];
+    int zeros = 0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        zeros += (dev[2 * i] == 0.0f) + (dev[2 * i + 1] == 0.0f);
+        kp[i] = ((__float_as_uint(dev[2 * i]) >> 16) & 0x7fffu) |
+                (__float_as_uint(dev[2 * i + 1]) & 0x7fff0000u);
+    }
+    zeros = wave_sum_small<8>(zeros);
+    const int total = 64 * R;
+    if (zeros == total) return __builtin_nan("");  // numpy: median of nothing
+    const int rank2 = total + zeros;  // zeros sort first (reference rank.mako:261-266)
+    const int rank = rank2 / 2;       // rank of the (upper) median among all slots
+    const bool even = !(rank2 & 1);
+    // 2. which key bin holds the median, and how many samples lie below the bin
+    unsigned K = 0;
+    int below_bin = 0;
+    for (int bit = 14; bit >= 0; bit--) {
+        const unsigned test = K | (1u << bit);
+        const int c = count_less16<NP>(kp, test);
+        if (c <= rank) {
+            K = test;
+            below_bin = c;
+        }
+    }
+    auto key_of = [&](int j) -> unsigned {
+        return (j & 1) ? (kp[j / 2] >> 16) : (kp[j / 2] & 0xffffu);
+    };
+    auto bin_mask = [&](unsigned key) -> unsigned long long {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (key_of(j) == key) m |= 1ull << j;
+        return m;
+    };
+    int in_bin = count_less16<NP>(kp, K + 1) - below_bin;
+    int r = rank - below_bin;  // 0-based rank inside the bin
+    unsigned long long cand = bin_mask(K);
+    if (in_bin > LIST_CAP) {
+        // Degenerate data (hundreds of samples in one key bin, e.g. quantised input):
+        // narrow the bin with an exact search on the full float32 patterns, which
+        // leaves only samples whose float32 deviations are identical.
+        unsigned cur = K << 16;
+        int below = below_bin;
+        for (int bit = 15; bit >= 0; bit--) {
+            const unsigned test = cur | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < R; j++) c += (__float_as_uint(dev[j]) & 0x7fffffffu) < test;
+            c = ksp_wave_sum(c);
+            if (c <= rank) {
+                cur = test;
+                below = c;
+            }
+        }
+        cand = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if ((__float_as_uint(dev[j]) & 0x7fffffffu) == cur) cand |= 1ull << j;
+        in_bin = ksp_wave_sum(__popcll(cand));
+        r = rank - below;
+        below_bin = below;
+        if (in_bin > LIST_CAP) {
+            // still too many: they share one float32 value. If their exact values are
+            // all equal (the usual reason), that value is the answer for rank r and
+            // r - 1 alike; otherwise give the float32 value (documented limitation).
+            double lo = __builtin_inf(), hi = 0.0;
+            unsigned long long todo = cand;
+            while (__any(todo != 0)) {
+                const bool has = todo != 0;
+                const int j = has ? __ffsll((long long)todo) - 1 : 0;
+                todo &= todo - 1;
+                const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
+                lo = has ? fmin(lo, x) : lo;
+                hi = has ? fmax(hi, x) : hi;
+            }
+            lo = ksp_wave_min(lo);
+            hi = ksp_wave_max(hi);
+            double xk = (lo == hi) ? lo : (double)__uint_as_float(cur);
+            if (even && r == 0) {
+                // lower median lies below this value: largest float32 value below it
+                float b32 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const float a = fabsf(dev[j]);
+                    b32 = (__float_as_uint(a) < cur) ? fmaxf(b32, a) : b32;
+                }
+                b32 = ksp_wave_max(b32);
+                unsigned long long bm = 0;
+#pragma unroll
+                for (int j = 0; j < R; j++)
+                    if (fabsf(dev[j]) == b32) bm |= 1ull << j;
+                const int n2 = gather_exact<WIDTH>(bm, c0, list, 0, LIST_CAP, fetch);
+                double below_max = 0.0;
+                for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
+                below_max = ksp_wave_max(below_max);
+                __builtin_amdgcn_wave_barrier();
+                xk = (xk + below_max) / 2.0;
+            }
+            return xk * FUSED_MAD_NORMAL;
+        }
+    }
+    // 3. recompute the bin's (few) samples exactly and rank them in float64
+    gather_exact<WIDTH>(cand, c0, list, 0, LIST_CAP, fetch);
+    double xk, prev;
+    bool have_prev;
+    rank_in_list(list, in_bin, r, lane, xk, prev, have_prev);
+    __builtin_amdgcn_wave_barrier();
+    if (even && !have_prev) {
+        // r == 0: the lower median is the largest value below the bin, i.e. the
+        // largest exact value of the highest non-empty bin below K
+        int k2 = -1;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int kj = (int)key_of(j);
+            k2 = (kj < (int)K) ? max(k2, kj) : k2;
+        }
+        k2 = wave_max_int(k2);
+        unsigned long long bm = bin_mask((unsigned)k2);
+        // within that bin the largest float32 values are enough
+        float b32 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if ((bm >> j) & 1) b32 = fmaxf(b32, fabsf(dev[j]));
+        b32 = ksp_wave_max(b32);
+        unsigned long long top = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (((bm >> j) & 1) && fabsf(dev[j]) == b32) top |= 1ull << j;
+        const int n2 = gather_exact<WIDTH>(top, c0, list, 0, LIST_CAP, fetch);
+        double below_max = 0.0;
+        for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
+        prev = ksp_wave_max(below_max);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (even) xk = (xk + prev) / 2.0;  // float64 mean, as numpy.median
+    return xk * FUSED_MAD_NORMAL;
+}
+
+// ---------------------------------------------------------------------------------
+// Thresholds. Returns the flag mask of the lane's run (bit j: channel c0 + j).
+//
+// SumThreshold is evaluated on the float32 deviations with a rigorous error bound:
+// |float32(d) - d| <= 2^-24 |d|, so a window sum computed from the rounded values is
+// within 2^-24 * sum|d| (plus float64 rounding, covered by using 2^-23) of the exact
+// float64 sum. Windows whose sum is further than that from the limit are decided as
+// the exact arithmetic would decide them; the others (practically never) are summed
+// again from exact deviations.
+template <int R, int WIDTH, class Fetch>
+__device__ __forceinline__ unsigned long long threshold_flags(const FusedParams &p,
+                                                              const float (&dev)[R], double dmax,
+                                                              double noise64, int lane, int C,
+                                                              Fetch &&fetch)
+{
+    static_assert(R <= 64, "flag mask is 64 bits");
+    const int c0 = lane * R;
+    unsigned long long fl = 0;
+    if (p.threshold_kind == KSP_THRESHOLD_SIMPLE) {
+        const double thr = p.n_sigma * noise64;  // float64 product (host.py:182)
+        if (__any(dmax > thr)) {
+            // float32(d) > thr decides d > thr except when float32(d) is within one
+            // rounding of thr; those samples are recomputed exactly
+            unsigned long long unsure = 0;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const double d = (double)dev[j];
+                const double slack = fabs(d) * 0x1p-23;
+                if (d - slack > thr)
+                    fl |= 1ull << j;
+                else if (d + slack > thr)
+                    unsure |= 1ull << j;
+            }
+            while (__any(unsure != 0)) {
+                const bool has = unsure != 0;
+                const int j = has ? __ffsll((long long)unsure) - 1 : 0;
+                unsure &= unsure - 1;
+                const double d = exact_dev<WIDTH>(c0 + j, fetch);
+                if (has && d > thr) fl |= 1ull << j;
+            }
+        }
+        return fl;
+    }
+    const double t1 = p.n_sigma * noise64;  // host.py:252
+    // (static indices only: a runtime-indexed array would live in scratch memory)
+    constexpr int MAXW = 4;
+    float thr[MAXW];
+    float thr_min = __builtin_inff();
+    bool thr_nan = false;
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) {
+        thr[k] = (float)(t1 * p.scales[k < KSP_MAX_WINDOWS ? k : 0]);  // host.py:235
+        if (k < p.n_windows) {
+            thr_min = fminf(thr_min, thr[k]);
+            thr_nan |= (thr[k] != thr[k]);
+        }
+    }
+    // Fast reject (exact): no window can fire unless some sample reaches
+    // min_k thr_k; the 2^-20 margin makes the test conservative; needs thresholds > 0.
+    const double cand = (double)thr_min * (1.0 - 0x1p-20);
+    const bool any = !(thr_min > 0.0f) || (dmax >= cand);
+    if (thr_nan || !__any(any)) return 0;
+
+    float d[R];  // working copy: deviations with flagged samples replaced by thr
+#pragma unroll
+    for (int j = 0; j < R; j++) d[j] = dev[j];
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) {
+        if (k >= p.n_windows) break;
+        const int w = 1 << k;
+        const float thrf = thr[k];
+        const double limit = (double)__fmul_rn(thrf, (float)w);  // host.py:242
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if ((fl >> j) & 1) d[j] = thrf;  // host.py:237 (exact: thr is a float32)
+        // the next lanes' first 7 values and flag bits (w - 1 <= 7 are used)
+        float ext[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) ext[m] = __shfl_down(d[m % R], 1 + m / R, 64);
+        unsigned nfl = 0;  // flag bits of the 7 channels after this run
+#pragma unroll
+        for (int m = 0; m < 7; m++) {
+            const unsigned long long f = __shfl_down(fl, 1 + m / R, 64);
+            nfl |= (unsigned)((f >> (m % R)) & 1) << m;
+        }
+        unsigned long long hits = 0, unsure = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            double s = 0.0, mag = 0.0;
+#pragma unroll
+            for (int m = 0; m < w; m++) {
+                {
+                    const int jj = j + m;
+                    const float v = (jj < R) ? d[jj % R] : ext[(jj >= R) ? (jj - R) % 7 : 0];
+                    const bool sub = (jj < R) ? ((fl >> (jj % 64)) & 1) : ((nfl >> ((jj >= R) ? (jj - R) % 7 : 0)) & 1);
+                    s += (double)v;
+                    mag += sub ? 0.0 : fabs((double)v);  // substituted values are exact
+                }
+            }
+            const bool valid = (c0 + j + w <= C);
+            const double slack = mag * 0x1p-23;
+            if (valid) {
+                if (s - slack > limit)
+                    hits |= 1ull << j;
+                else if (s + slack > limit)
+                    unsure |= 1ull << j;
+            }
+        }
+        // resolve the (practically non-existent) undecided windows exactly
+        while (__any(unsure != 0)) {
+            const bool has = unsure != 0;
+            const int j = has ? __ffsll((long long)unsure) - 1 : 0;
+            unsure &= unsure - 1;
+            double s = 0.0;
+            for (int m = 0; m < w; m++) {
+                const int jj = j + m;
+                const bool sub = (jj < R) ? ((fl >> jj) & 1) : ((nfl >> (jj - R)) & 1);
+                const double x = exact_dev<WIDTH>(c0 + jj, fetch);
+                s += sub ? (double)thrf : x;
+            }
+            if (has && s > limit) hits |= 1ull << j;
+        }
+        // dilation: a hit at j flags j..j+w-1. `pin` holds the hits of the 7 positions
+        // just below this lane's run (bit i <-> position i - 7).
+        unsigned pin = 0;
+        if (R >= 7) {
+            const unsigned long long prev = __shfl_up(hits, 1, 64);
+            if (lane > 0) pin = (unsigned)(prev >> (R - 7)) & 0x7fu;
+        } else {
+#pragma unroll
+            for (int back = 1; back * R < 7 + R; back++) {
+                const unsigned long long prev = __shfl_up(hits, back, 64);
+                const int sh = 7 - back * R;
+                if (lane >= back) pin |= (unsigned)(sh >= 0 ? (prev << sh) : (prev >> (-sh))) & 0x7fu;
+            }
+        }
+        unsigned long long own = hits;
+        if (w >= 2) { own |= own << 1; pin |= pin << 1; }
+        if (w >= 4) { own |= own << 2; pin |= pin << 2; }
+        if (w >= 8) { own |= own << 4; pin |= pin << 4; }
+        const unsigned long long comb = own | (unsigned long long)(pin >> 7);
+        fl |= comb & (R == 64 ? ~0ull : ((1ull << R) - 1));
+    }
+    return fl;
+}
+
+// Flags: the launcher zero-fills the whole array (one coalesced memset on the same
+// stream); only flagged samples are written here, one byte each. A strip is 8 bytes
+// wide, which no store pattern of one workgroup can turn into full 64-byte lines;
+// flags are rare, the memset is not.
+__device__ __forceinline__ void write_flags(const FusedParams &p, unsigned long long fl, int c0,
+                                            int bl, int C)
+{
+    if (bl >= p.baselines) return;
+    const uint8_t fv = (uint8_t)p.flag_value;
+    while (fl) {
+        const int j = __ffsll((long long)fl) - 1;
+        fl &= fl - 1;
+        const int c = c0 + j;
+        if (c < C) p.flags[(size_t)c * p.flags_stride + bl] = fv;
+    }
+}
