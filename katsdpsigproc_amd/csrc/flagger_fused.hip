@@ -6,29 +6,24 @@
 // flag written once (1 B); everything in between stays on chip.
 //
 // Work decomposition ("strip" = 8 adjacent baselines x all channels):
-//   * one 512-thread workgroup (8 wavefronts) per CU works on one strip at a time;
-//   * the strip is read as 64-byte row segments, turned into numpy's |z| and parked
-//     as float32 in LDS, transposed to [baseline][channel] (136 KiB of 160 KiB);
-//   * from then on wavefront w owns baseline w and lane l a run of R consecutive
-//     channels: the sliding median (median_window.h), the MAD selection and
-//     SumThreshold are wave-local, cross-lane traffic goes through shuffles/ballots;
-//   * deviations live in float64 registers: the host path is float64 after the
-//     amplitude (reference rfi/host.py:148-163, 235-245) and flags must match it.
-//
-// Two kernels share those phases (fused_common.h):
-//   flagger_fused_kernel  one strip per workgroup; every option (input flags, ragged
-//                         shapes, amplitude input, deviations output).
-//   flagger_pipe_kernel   persistent and software-pipelined: while a wavefront slides
-//                         its median over strip k, every step also requests one sample
-//                         of strip k+1 per lane, and turns the sample requested 16 steps
-//                         earlier into an amplitude that overwrites an LDS slot strip k no
-//                         longer needs. HBM latency, the amplitude arithmetic and the
-//                         median therefore overlap instead of queueing behind a barrier.
+//   * persistent 512-thread workgroups (8 wavefronts), one per CU, each walking over
+//     strips; a strip is read as 64-byte row segments, turned into numpy's |z| and
+//     parked as float32 in LDS, transposed to [baseline][channel] (146 KiB of 160 KiB);
+//   * wavefront w then owns baseline w and lane l a run of R consecutive channels: the
+//     sliding median (median_window.h), the MAD selection and SumThreshold are
+//     wave-local (no workgroup barrier between them); cross-lane traffic goes through
+//     shuffles, ballots and the wavefront's own LDS row;
+//   * deviations are computed in float64 like the host path (reference
+//     rfi/host.py:148-163, 235-245), stored rounded to float32 over the dead amplitudes
+//     in LDS, and every decision that could depend on the rounding is re-taken from an
+//     exact float64 recomputation (fused_common.h), so flags are bit-identical;
+//   * software pipeline: the 16-byte loads of strip k+1 are issued into registers
+//     before strip k is processed and consumed after it, so HBM latency is hidden
+//     behind a whole strip of arithmetic although only one workgroup fits a CU.
 //
 // Roofline: HBM, 9 algorithmic bytes per sample (8 read + 1 written).
 #include "fused_common.h"
 
-// =================================================================================
 template <int R, int WIDTH>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const FusedParams p)
 {
@@ -38,156 +33,63 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int C = p.channels;
-    const int b0 = strip_of(blockIdx.x, p.n_strips) * FUSED_STRIP;
-
-    load_strip<R>(p, lds, b0, tid);
-    __syncthreads();
-    if (p.debug_stop == 1) return;
-
-    const int bl = b0 + wave;
     float *myrow = lds + wave * LY::ROW;
-    double *list = (double *)(lds + LY::LDS_FLOATS) + wave * LY::LIST_DOUBLES;
-    // amplitude of any channel of this baseline, for exact recomputation (LDS copy)
-    auto fetch = [&](int c) -> float {
-        return (c >= 0 && c < C) ? myrow[LY::index(c)] : __builtin_nanf("");
-    };
-    float dev[R];
-    double dmax;
-    median_phase<R, WIDTH>(myrow, lane, C, dev, dmax, [](int) {});
-    if (p.debug_stop == 2) {
-        float acc = (float)dmax;
-#pragma unroll
-        for (int j = 0; j < R; j++) acc += dev[j];
-        if (acc == 12345.678f && p.noise) p.noise[0] = acc;  // keep the work alive
-        return;
-    }
-
-    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch);
-    if (lane == 0 && p.noise != nullptr && bl < p.baselines) p.noise[bl] = (float)noise64;
-    if (p.debug_stop == 3) return;
-
-    const unsigned long long fl =
-        threshold_flags<R, WIDTH>(p, dev, dmax, noise64, lane, C, fetch);
-    if (p.debug_stop == 4) {
-        if (fl == 0x123456789abcull && p.noise) p.noise[0] = 1.0f;
-        return;
-    }
-
-    if (p.deviations != nullptr) {
-        // stage float32 deviations in this wavefront's LDS row (the amplitudes are no
-        // longer needed), then write them as [channel][8 baselines]
-#pragma unroll
-        for (int j = 0; j < R; j++) myrow[lane * LY::RUN + j] = dev[j];
-        __syncthreads();
-        const int q = tid & 3, r0 = tid >> 2;
-        const int blq = b0 + 2 * q;
-        for (int row = r0; row < C; row += FUSED_THREADS / 4) {
-            const int idx = LY::index(row);
-            const float v0 = lds[(2 * q) * LY::ROW + idx];
-            const float v1 = lds[(2 * q + 1) * LY::ROW + idx];
-            float *dst = p.deviations + (size_t)row * p.dev_stride + blq;
-            if (blq + 1 < p.baselines && (p.dev_stride & 1) == 0)
-                *(float2 *)dst = make_float2(v0, v1);
-            else {
-                if (blq < p.baselines) dst[0] = v0;
-                if (blq + 1 < p.baselines) dst[1] = v1;
-            }
-        }
-    }
-    write_flags(p, fl, lane * R, bl, C);
-}
-
-// =================================================================================
-// Persistent, software-pipelined variant. Requirements (checked by the launcher):
-// complex64 input, channels == 64 * R, baselines a multiple of 8, no deviations output.
-//
-// Prefetch schedule for the NEXT strip, per lane and per median step j (0..R-1):
-//   "op" i (0..R-1) handles channel offset q_i = (i + 6) % R inside every lane run,
-//   i.e. row l' * R + q_i for l' = tid / 8 and baseline tid % 8 (8 lanes = one 64-byte
-//   row segment). Op i is issued (global load) at step max(0, i + 9 - D) and consumed
-//   (amplitude -> LDS) at step i + 9; ops that would be consumed after the last step
-//   run in a tail behind a barrier. Slot q = i + 6 was last read (as the sample
-//   entering a window) at step q - 6 = i, so with a workgroup barrier every 4 steps no
-//   wavefront can still need it at step i + 9; offsets 0..5 are read late (by the lane
-//   below, steps R-6..R-1) and are therefore the last ops, in the tail.
-template <int R, int WIDTH>
-__global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_pipe_kernel(const FusedParams p)
-{
-    using LY = FusedLayout<R>;
-    constexpr int D = 16;     // loads in flight per lane
-    constexpr int LAG = 9;    // steps between the last use of a slot and its overwrite
-    constexpr int LOOP_OPS = R - LAG;  // ops consumed inside the median loop
-    static_assert(R >= 32 && R % 4 == 0, "schedule assumes runs of at least 32 channels");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int C = p.channels;
-
-    float *myrow = lds + wave * LY::ROW;
-    double *list = (double *)(lds + LY::LDS_FLOATS) + wave * LY::LIST_DOUBLES;
-    // prefetch role of this lane: row l' * R + q of baseline pb within the strip
-    const int pl = tid >> 3;  // l' (0..63)
-    const int pb = tid & 7;
-    float *pslot = lds + pb * LY::ROW + pl * LY::RUN;
+    double *list = (double *)(lds + LY::LDS_FLOATS) + wave * LY::LIST_STRIDE;
 
     int id = blockIdx.x;
     if (id >= p.n_strips) return;
-    load_strip<R>(p, lds, strip_of(id, p.n_strips) * FUSED_STRIP, tid);
-    __syncthreads();
+    StripLoader<R> loader;
+    loader.request(p, strip_of(id, p.n_strips) * FUSED_STRIP, tid);
 
     for (; id < p.n_strips; id += gridDim.x) {
         const int b0 = strip_of(id, p.n_strips) * FUSED_STRIP;
         const int bl = b0 + wave;
+        // strip k: requests (issued one iteration ago) -> amplitudes in LDS
+        loader.finish(p, lds, b0, tid);
+        __syncthreads();
+        // strip k+1: its requests stay in flight during everything below
         const int next = id + gridDim.x;
-        const bool has_next = next < p.n_strips;  // workgroup-uniform
-        const int nb = (has_next ? strip_of(next, p.n_strips) : 0) * FUSED_STRIP + pb;
-        const float2 *nsrc = (const float2 *)p.vis + (size_t)pl * R * p.vis_stride + nb;
+        if (next < p.n_strips) loader.request(p, strip_of(next, p.n_strips) * FUSED_STRIP, tid);
+        if (p.debug_stop == 1) return;
 
-        float2 pf[D];
-        auto issue = [&](int i) {  // request op i
-            const int q = (i + 6) % R;
-            pf[i % D] = nsrc[(size_t)q * p.vis_stride];
-        };
-        auto consume = [&](int i) {  // op i: amplitude -> LDS slot (dead in strip k)
-            const int q = (i + 6) % R;
-            const float2 v = pf[i % D];
-            pslot[q] = amp_with_flags(p, v.x, v.y, pl * R + q, nb);
-        };
+        const double dmax = median_phase<R, WIDTH>(p, bl, myrow, lane, C);
+        if (p.debug_stop == 2) {
+            if (dmax == 12345.678 && p.noise) p.noise[0] = 1.f;  // keep the work alive
+            return;
+        }
+        const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(p, bl, myrow, lane, list);
+        if (lane == 0 && p.noise != nullptr && bl < p.baselines) p.noise[bl] = (float)noise64;
+        if (p.debug_stop == 3) return;
 
-        // amplitude of any channel of this baseline, for exact recomputation: the LDS
-        // copy is overwritten by the next strip, so go back to memory (a few dozen
-        // 8-byte reads per baseline, served by L2 / Infinity Cache)
-        auto fetch = [&](int c) -> float {
-            if (c < 0 || c >= C) return __builtin_nanf("");
-            const float2 v = ((const float2 *)p.vis)[(size_t)c * p.vis_stride + bl];
-            return amp_with_flags(p, v.x, v.y, c, bl);
-        };
-        float dev[R];
-        double dmax;
-        median_phase<R, WIDTH>(myrow, lane, C, dev, dmax, [&](int j) {
-            if (has_next) {
-                if (j >= LAG && j - LAG < LOOP_OPS) consume(j - LAG);
-                if (j == 0) {
-#pragma unroll
-                    for (int i = 0; i <= D - LAG; i++) issue(i);
-                } else if (j + D - LAG < R)
-                    issue(j + D - LAG);
+        if (p.deviations != nullptr) {
+            // the rows hold the float32 deviations: write them as [channel][8 baselines]
+            // before the threshold stage may use them as scratch
+            __syncthreads();
+            const int q = tid & 3, r0 = tid >> 2;
+            const int blq = b0 + 2 * q;
+            for (int row = r0; row < C; row += FUSED_THREADS / 4) {
+                const int slot = LY::dev_slot(row);
+                const float v0 = lds[(2 * q) * LY::ROW + slot];
+                const float v1 = lds[(2 * q + 1) * LY::ROW + slot];
+                float *dst = p.deviations + (size_t)row * p.dev_stride + blq;
+                if (blq + 1 < p.baselines && (p.dev_stride & 1) == 0)
+                    *(float2 *)dst = make_float2(v0, v1);
+                else {
+                    if (blq < p.baselines) dst[0] = v0;
+                    if (blq + 1 < p.baselines) dst[1] = v1;
+                }
             }
-            if ((j & 3) == 3) __syncthreads();  // keeps the wavefronts within 4 steps
-        });
-        if (has_next) {
-            __syncthreads();  // every wavefront has finished reading strip k
-#pragma unroll
-            for (int i = LOOP_OPS; i < R; i++) consume(i);
+            __syncthreads();
         }
 
-        const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch);
-        if (lane == 0 && p.noise != nullptr) p.noise[bl] = (float)noise64;
         const unsigned long long fl =
-            threshold_flags<R, WIDTH>(p, dev, dmax, noise64, lane, C, fetch);
+            threshold_flags<R, WIDTH>(p, bl, myrow, dmax, noise64, lane, C);
+        if (p.debug_stop == 4) {
+            if (fl == 0x123456789abcull && p.noise) p.noise[0] = 1.0f;
+            return;
+        }
         write_flags(p, fl, lane * R, bl, C);
-        __syncthreads();  // strip k+1 is complete in LDS
+        __syncthreads();  // every wavefront is done with strip k's LDS image
     }
 }
 
@@ -196,40 +98,26 @@ template <int R, int WIDTH>
 static int launch_fused(hipStream_t s, const FusedParams &p, int cus)
 {
     using LY = FusedLayout<R>;
-    const size_t lds_bytes = LY::LDS_BYTES;
-    // all flags start at zero; the kernels only write the (rare) non-zero ones
+    auto kern = flagger_fused_kernel<R, WIDTH>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        KSP_CHECK(hipFuncSetAttribute((const void *)kern,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // all flags start at zero; the kernel only writes the (rare) non-zero ones
     KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
                              s));
-    // the pipelined kernel is opt-in (KSP_FUSED_PIPELINE=1) until it beats the plain one
-    const char *pipe = getenv("KSP_FUSED_PIPELINE");
-    const bool pipelined = R >= 32 && p.channels == 64 * R && !p.is_amplitude &&
-                           p.deviations == nullptr && (p.baselines % FUSED_STRIP) == 0 &&
-                           p.debug_stop == 0 && (pipe && pipe[0] == '1');
-    if (pipelined) {
-        if constexpr (R >= 32) {
-            auto kern = flagger_pipe_kernel<R, WIDTH>;
-            static bool attr_set = false;
-            if (!attr_set) {
-                KSP_CHECK(hipFuncSetAttribute((const void *)kern,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              160 * 1024));
-                attr_set = true;
-            }
-            // one workgroup per CU (LDS-limited)
-            int grid = cus > 0 ? cus : 256;
-            if (grid > p.n_strips) grid = p.n_strips;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds_bytes, s, p);
-        }
-    } else {
-        auto kern = flagger_fused_kernel<R, WIDTH>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            KSP_CHECK(hipFuncSetAttribute((const void *)kern,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
-    }
+    // persistent grid: as many workgroups as fit the chip at once (LDS allows one per CU
+    // for R = 64, more for the small-band variants)
+    int per_cu = (int)((160 * 1024) / LY::LDS_BYTES);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    int grid = (cus > 0 ? cus : 256) * per_cu;
+    const char *g = getenv("KSP_FUSED_GRID");  // diagnostic override
+    if (g && atoi(g) > 0) grid = atoi(g);
+    if (grid > p.n_strips) grid = p.n_strips;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), LY::LDS_BYTES, s, p);
     KSP_LAUNCH_CHECK();
     return 0;
 }
