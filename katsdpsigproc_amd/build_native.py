@@ -47,6 +47,9 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source and link the shared library; returns its path."""
     hipcc = _hipcc()
+    extra = os.environ.get("KSP_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
+    if extra:
+        force = True
     os.makedirs(OUT_DIR, exist_ok=True)
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
@@ -58,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OUT_DIR, os.path.basename(src)[:-4] + ".o")
         objects.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

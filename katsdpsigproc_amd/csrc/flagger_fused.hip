@@ -5,25 +5,30 @@
 // per sample through device memory. Here each visibility is read once (8 B) and each
 // flag written once (1 B); everything in between stays on chip.
 //
-// Work decomposition ("strip" = 8 adjacent baselines x all channels):
-//   * persistent 512-thread workgroups (8 wavefronts), one per CU, each walking over
-//     strips; a strip is read as 64-byte row segments, turned into numpy's |z| and
-//     parked as float32 in LDS, transposed to [baseline][channel] (146 KiB of 160 KiB);
-//   * wavefront w then owns baseline w and lane l a run of R consecutive channels: the
-//     sliding median (median_window.h), the MAD selection and SumThreshold are
-//     wave-local (no workgroup barrier between them); cross-lane traffic goes through
-//     shuffles, ballots and the wavefront's own LDS row;
-//   * deviations are computed in float64 like the host path (reference
-//     rfi/host.py:148-163, 235-245), stored rounded to float32 over the dead amplitudes
-//     in LDS, and every decision that could depend on the rounding is re-taken from an
-//     exact float64 recomputation (fused_common.h), so flags are bit-identical;
-//   * software pipeline: the 16-byte loads of strip k+1 are issued into registers
-//     before strip k is processed and consumed after it, so HBM latency is hidden
-//     behind a whole strip of arithmetic although only one workgroup fits a CU.
+// Work decomposition ("strip" = FUSED_STRIP (4) adjacent baselines x all channels):
+//   * one 256-thread workgroup (4 wavefronts) works on one strip; its LDS image is
+//     ~76 KiB, so two workgroups share a CU and one's loads overlap the other's
+//     arithmetic. strip_of() hands neighbouring strips to the same XCD at the same
+//     time so that the 32-byte row segments of a 128-byte line meet in that XCD's L2;
+//   * the strip is read as row segments (8 rows in flight per lane, double buffered),
+//     turned into numpy's |z| and parked as float32 in LDS, transposed to
+//     [baseline][channel];
+//   * from then on wavefront w owns baseline w and lane l a run of R consecutive
+//     channels: the sliding median (median_window.h), the MAD selection and
+//     SumThreshold are wave-local, cross-lane traffic goes through shuffles/ballots;
+//   * deviations are kept as float32 in registers (rounding is monotone, so ordering
+//     decisions can be filtered on them); every value that decides a result - the
+//     MAD's median candidates, window sums within their error bound of a threshold -
+//     is recomputed exactly in float64 from the LDS amplitudes, because the host path
+//     is float64 after the amplitude (reference rfi/host.py:148-163, 235-245) and the
+//     flags must match it bit for bit.
+//   * flags are zero-filled by a memset node ahead of the kernel; the kernel only
+//     writes the (sparse) non-zero bytes.
 //
 // Roofline: HBM, 9 algorithmic bytes per sample (8 read + 1 written).
 #include "fused_common.h"
 
+// =================================================================================
 template <int R, int WIDTH>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const FusedParams p)
 {
@@ -33,91 +38,83 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int C = p.channels;
+    const int b0 = strip_of(blockIdx.x, p.n_strips) * FUSED_STRIP;
+
+    load_strip<R>(p, lds, b0, tid);
+    __syncthreads();
+    if (p.debug_stop == 1) return;
+
+    const int bl = b0 + wave;
     float *myrow = lds + wave * LY::ROW;
-    double *list = (double *)(lds + LY::LDS_FLOATS) + wave * LY::LIST_STRIDE;
-
-    int id = blockIdx.x;
-    if (id >= p.n_strips) return;
-    StripLoader<R> loader;
-    loader.request(p, strip_of(id, p.n_strips) * FUSED_STRIP, tid);
-
-    for (; id < p.n_strips; id += gridDim.x) {
-        const int b0 = strip_of(id, p.n_strips) * FUSED_STRIP;
-        const int bl = b0 + wave;
-        // strip k: requests (issued one iteration ago) -> amplitudes in LDS
-        loader.finish(p, lds, b0, tid);
-        __syncthreads();
-        // strip k+1: its requests stay in flight during everything below
-        const int next = id + gridDim.x;
-        if (next < p.n_strips) loader.request(p, strip_of(next, p.n_strips) * FUSED_STRIP, tid);
-        if (p.debug_stop == 1) return;
-
-        const double dmax = median_phase<R, WIDTH>(p, bl, myrow, lane, C);
-        if (p.debug_stop == 2) {
-            if (dmax == 12345.678 && p.noise) p.noise[0] = 1.f;  // keep the work alive
-            return;
-        }
-        const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(p, bl, myrow, lane, list);
-        if (lane == 0 && p.noise != nullptr && bl < p.baselines) p.noise[bl] = (float)noise64;
-        if (p.debug_stop == 3) return;
-
-        if (p.deviations != nullptr) {
-            // the rows hold the float32 deviations: write them as [channel][8 baselines]
-            // before the threshold stage may use them as scratch
-            __syncthreads();
-            const int q = tid & 3, r0 = tid >> 2;
-            const int blq = b0 + 2 * q;
-            for (int row = r0; row < C; row += FUSED_THREADS / 4) {
-                const int slot = LY::dev_slot(row);
-                const float v0 = lds[(2 * q) * LY::ROW + slot];
-                const float v1 = lds[(2 * q + 1) * LY::ROW + slot];
-                float *dst = p.deviations + (size_t)row * p.dev_stride + blq;
-                if (blq + 1 < p.baselines && (p.dev_stride & 1) == 0)
-                    *(float2 *)dst = make_float2(v0, v1);
-                else {
-                    if (blq < p.baselines) dst[0] = v0;
-                    if (blq + 1 < p.baselines) dst[1] = v1;
-                }
-            }
-            __syncthreads();
-        }
-
-        const unsigned long long fl =
-            threshold_flags<R, WIDTH>(p, bl, myrow, dmax, noise64, lane, C);
-        if (p.debug_stop == 4) {
-            if (fl == 0x123456789abcull && p.noise) p.noise[0] = 1.0f;
-            return;
-        }
-        write_flags(p, fl, lane * R, bl, C);
-        __syncthreads();  // every wavefront is done with strip k's LDS image
+    double *list = (double *)(lds + LY::LDS_FLOATS) + wave * LY::LIST_DOUBLES;
+    // amplitude of any channel of this baseline, for exact recomputation (LDS copy)
+    auto fetch = [&](int c) -> float {
+        return (c >= 0 && c < C) ? myrow[LY::index(c)] : __builtin_nanf("");
+    };
+    float dev[R];
+    double dmax;
+    median_phase<R, WIDTH>(myrow, lane, C, dev, dmax, [](int) {});
+    if (p.debug_stop == 2) {
+        float acc = (float)dmax;
+#pragma unroll
+        for (int j = 0; j < R; j++) acc += dev[j];
+        if (acc == 12345.678f && p.noise) p.noise[0] = acc;  // keep the work alive
+        return;
     }
+
+    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch);
+    if (lane == 0 && p.noise != nullptr && bl < p.baselines) p.noise[bl] = (float)noise64;
+    if (p.debug_stop == 3) return;
+
+    const unsigned long long fl =
+        threshold_flags<R, WIDTH>(p, dev, dmax, noise64, lane, C, fetch);
+    if (p.debug_stop == 4) {
+        if (fl == 0x123456789abcull && p.noise) p.noise[0] = 1.0f;
+        return;
+    }
+
+    if (p.deviations != nullptr) {
+        // stage float32 deviations in this wavefront's LDS row (the amplitudes are no
+        // longer needed), then write them as [channel][8 baselines]
+#pragma unroll
+        for (int j = 0; j < R; j++) myrow[lane * LY::RUN + j] = dev[j];
+        __syncthreads();
+        constexpr int LPR = FUSED_STRIP / 2;
+        const int q = tid % LPR, r0 = tid / LPR;
+        const int blq = b0 + 2 * q;
+        for (int row = r0; row < C; row += FUSED_THREADS / LPR) {
+            const int idx = LY::index(row);
+            const float v0 = lds[(2 * q) * LY::ROW + idx];
+            const float v1 = lds[(2 * q + 1) * LY::ROW + idx];
+            float *dst = p.deviations + (size_t)row * p.dev_stride + blq;
+            if (blq + 1 < p.baselines && (p.dev_stride & 1) == 0)
+                *(float2 *)dst = make_float2(v0, v1);
+            else {
+                if (blq < p.baselines) dst[0] = v0;
+                if (blq + 1 < p.baselines) dst[1] = v1;
+            }
+        }
+    }
+    write_flags(p, fl, lane * R, bl, C);
 }
 
 // =================================================================================
 template <int R, int WIDTH>
-static int launch_fused(hipStream_t s, const FusedParams &p, int cus)
+static int launch_fused(hipStream_t s, const FusedParams &p)
 {
     using LY = FusedLayout<R>;
+    const size_t lds_bytes = LY::LDS_BYTES;
+    // all flags start at zero; the kernels only write the (rare) non-zero ones
+    KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
+                             s));
     auto kern = flagger_fused_kernel<R, WIDTH>;
-    static bool attr_set = false;  // per instantiation
+    static bool attr_set = false;
     if (!attr_set) {
         KSP_CHECK(hipFuncSetAttribute((const void *)kern,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    // all flags start at zero; the kernel only writes the (rare) non-zero ones
-    KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
-                             s));
-    // persistent grid: as many workgroups as fit the chip at once (LDS allows one per CU
-    // for R = 64, more for the small-band variants)
-    int per_cu = (int)((160 * 1024) / LY::LDS_BYTES);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
-    int grid = (cus > 0 ? cus : 256) * per_cu;
-    const char *g = getenv("KSP_FUSED_GRID");  // diagnostic override
-    if (g && atoi(g) > 0) grid = atoi(g);
-    if (grid > p.n_strips) grid = p.n_strips;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), LY::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
     KSP_LAUNCH_CHECK();
     return 0;
 }
@@ -183,16 +180,8 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     for (int k = 0; k < KSP_MAX_WINDOWS; k++)
         p.scales[k] = (scales64 != nullptr && k < n_windows) ? scales64[k] : 0.0;
 
-    static int cus[64] = {0};
-    if (device >= 0 && device < 64 && cus[device] == 0) {
-        hipDeviceProp_t prop;
-        KSP_CHECK(hipGetDeviceProperties(&prop, device));
-        cus[device] = prop.multiProcessorCount;
-    }
-    const int n_cu = (device >= 0 && device < 64) ? cus[device] : 256;
-
     hipStream_t s = (hipStream_t)stream;
-    if (channels <= 64 * 4) return launch_fused<4, 13>(s, p, n_cu);
-    if (channels <= 64 * 16) return launch_fused<16, 13>(s, p, n_cu);
-    return launch_fused<64, 13>(s, p, n_cu);
+    if (channels <= 64 * 4) return launch_fused<4, 13>(s, p);
+    if (channels <= 64 * 16) return launch_fused<16, 13>(s, p);
+    return launch_fused<64, 13>(s, p);
 }

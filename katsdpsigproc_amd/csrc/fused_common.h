@@ -1,13 +1,15 @@
-// Building blocks of the fused flagger kernel (flagger_fused.hip): strip layout in
-// LDS, cooperative strip load, and the wave-local median / MAD / threshold phases.
-// See DESIGN.md section 4.1 for the reasoning.
+// Building blocks shared by the fused flagger kernels (flagger_fused.hip):
+// strip layout in LDS, cooperative strip load, the wave-local median / MAD /
+// threshold phases, flag output. See DESIGN.md section 4.1 for the reasoning.
 #pragma once
 #include <stdlib.h>
 
 #include "median_window.h"
 
-#define FUSED_THREADS 512
-#define FUSED_STRIP 8
+#ifndef FUSED_STRIP
+#define FUSED_STRIP 4  // baselines per workgroup (one wavefront each); 4 -> two workgroups per CU
+#endif
+#define FUSED_THREADS (64 * FUSED_STRIP)
 #define FUSED_MAD_NORMAL 1.4826
 
 struct FusedParams {
@@ -25,40 +27,25 @@ struct FusedParams {
     double scales[KSP_MAX_WINDOWS];
 };
 
-// LDS image of one strip: 8 rows (one per baseline) of float32. Lane l of the owning
-// wavefront works on channels [l*R, (l+1)*R): its run starts at word l*RUN. RUN is ODD
-// so that the 64 lanes of a wavefront, all reading the same offset of their own run, hit
-// 32 different banks; the 9 pad words per run hold the first 6 deviations (see
-// dev_slot). Rows are 8 words apart modulo 32 so that the baselines written by one
-// lane group during the load fall in different banks. After the rows: one small
-// candidate list per wavefront for the MAD.
+// LDS image of one strip: 8 rows (one per baseline) of float32 amplitudes. Lane l of
+// the owning wavefront works on channels [l*R, (l+1)*R); its run is padded by 4 words
+// so that 16-byte reads of consecutive lanes fall in consecutive 16-byte slots, and
+// rows are offset by 8 words so that the 8 baselines written by one lane group hit
+// different banks. After the rows: one candidate list per wavefront for the MAD.
 template <int R>
 struct FusedLayout {
-    static constexpr int PAD = 9;
-    static constexpr int RUN = R + PAD;
-    static constexpr int ROW = ((64 * RUN + 31) / 32) * 32 + 8;
+    static constexpr int RUN = R + 4;
+    static constexpr int ROW = 64 * RUN + 8;
     static constexpr int LDS_FLOATS = FUSED_STRIP * ROW;
-    static constexpr int LIST_DOUBLES = 128;                             // candidates
-    static constexpr int LIST_STRIDE = LIST_DOUBLES + LIST_DOUBLES / 2;  // + as many ints
+    static constexpr int LIST_DOUBLES = 256;  // per wavefront
     static constexpr size_t LDS_BYTES =
-        sizeof(float) * LDS_FLOATS + sizeof(double) * LIST_STRIDE * FUSED_STRIP;
-    // word of the AMPLITUDE of channel c within a row
-    __device__ static __forceinline__ int amp_slot(int c) { return (c / R) * RUN + (c % R); }
-    // word of the DEVIATION of channel c within a row: deviations overwrite amplitudes
-    // in place once these are dead, except for the first 6 channels of a run, which the
-    // lane below still reads late (as the tail of its own windows) and which therefore
-    // go to the pad words.
-    __device__ static __forceinline__ int dev_slot(int c)
-    {
-        const int j = c % R;
-        return (c / R) * RUN + (j < 6 ? R + j : j);
-    }
+        sizeof(float) * LDS_FLOATS + sizeof(double) * LIST_DOUBLES * FUSED_STRIP;
+    __device__ static __forceinline__ int index(int c) { return (c / R) * RUN + (c % R); }
 };
-static_assert(FusedLayout<64>::LDS_BYTES <= 160 * 1024, "LDS image must fit one CU");
 
 // blockIdx -> strip, XCD-aware: workgroups b, b+8, ... share an XCD, so the 8 strips
-// that make up one 512-byte input line are given to workgroups of one XCD, where their
-// half-lines meet in L2. Speed only -- any bijection is correct.
+// that make up one 512-byte input line / 64-byte output line are given to workgroups
+// of one XCD. Speed only -- any bijection is correct.
 __device__ __forceinline__ int strip_of(int id, int n_strips)
 {
     const int full = (n_strips / 64) * 64;
@@ -79,202 +66,141 @@ __device__ __forceinline__ float amp_with_flags(const FusedParams &p, float re, 
     return a;
 }
 
-// ---------------------------------------------------------------------------------
-// Strip load, split in two halves so that the memory requests of strip k+1 can be in
-// flight while strip k is being processed: `request` issues every 16-byte load of a
-// lane (a pair of baselines = a quarter of a 64-byte row segment, every 128th row);
-// `finish` turns them into numpy's |z| and stores the float32 amplitudes in LDS.
-// NROWS = ceil(C / 128) requests per lane stay in registers in between.
+// Cooperative load of a whole strip: vis -> amplitude -> LDS rows. Each lane owns a
+// pair of baselines (16 B of the row segment) and every RSTEP-th row. Requests are
+// issued LB rows at a time, one batch ahead of the amplitude arithmetic (double
+// buffered in registers).
 template <int R>
-struct StripLoader {
+__device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int b0, int tid)
+{
     using LY = FusedLayout<R>;
-    static constexpr int RSTEP = FUSED_THREADS / 4;                   // rows covered per pass
-    static constexpr int NROWS = (64 * R + RSTEP - 1) / RSTEP;        // rows per lane
-#ifndef KSP_PREFETCH_ROWS
-#define KSP_PREFETCH_ROWS 0
-#endif
-    // rows requested ahead of time and held in registers while the previous strip is
-    // processed; the rest is loaded when the strip is finished (registers are finite:
-    // a spilled request would have to be waited for at once, which defeats the purpose)
-    static constexpr int NPRE = NROWS < KSP_PREFETCH_ROWS ? NROWS : KSP_PREFETCH_ROWS;
-    float4 raw[NPRE];
-
-    // fast path: complex64 input and both baselines of the pair exist
-    __device__ __forceinline__ static bool plain(const FusedParams &p, int b0, int tid)
-    {
-        return !p.is_amplitude && (b0 + 2 * (tid & 3) + 1 < p.baselines);
-    }
-
-    __device__ __forceinline__ void request(const FusedParams &p, int b0, int tid)
-    {
-        const int bl = b0 + 2 * (tid & 3);
-        const int r0 = tid >> 2;
-        const bool ok = plain(p, b0, tid);
+    constexpr int LB = 8;
+    constexpr int LPR = FUSED_STRIP / 2;            // lanes per row segment
+    constexpr int RSTEP = FUSED_THREADS / LPR;      // rows covered per pass
+    const int C = p.channels;
+    const int q = tid % LPR;
+    const int r0 = tid / LPR;
+    const int bl = b0 + 2 * q;
+    const bool ok0 = bl < p.baselines, ok1 = bl + 1 < p.baselines;
+    const bool plain = !p.is_amplitude && ok1;
+    auto request = [&](float4 (&raw)[LB], int rbase) {
 #pragma unroll
-        for (int u = 0; u < NPRE; u++) {
-            const int row = r0 + u * RSTEP;
+        for (int u = 0; u < LB; u++) {
+            const int row = rbase + u * RSTEP;
             raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && row < p.channels)
+            if (plain && row < C)
                 raw[u] = *(const float4 *)((const float2 *)p.vis + (size_t)row * p.vis_stride + bl);
         }
-    }
-
-    // Input flags are NOT applied here (the median phase masks the samples as it reads
-    // them), which keeps this fully unrolled block small.
-    __device__ __forceinline__ void finish(const FusedParams &p, float *lds, int b0, int tid)
-    {
-        const int q = tid & 3;
-        const int bl = b0 + 2 * q;
-        const int r0 = tid >> 2;
-        const bool ok0 = bl < p.baselines, ok1 = bl + 1 < p.baselines;
-        const bool ok = plain(p, b0, tid);
-        if (ok) {
+    };
+    auto finish = [&](const float4 (&raw)[LB], int rbase) {
 #pragma unroll
-            for (int u = 0; u < NPRE; u++) {
-                const int row = r0 + u * RSTEP;
-                if (row >= p.channels) break;
-                const int slot = LY::amp_slot(row);
-                lds[(2 * q) * LY::ROW + slot] = ksp_abs_c64(raw[u].x, raw[u].y);
-                lds[(2 * q + 1) * LY::ROW + slot] = ksp_abs_c64(raw[u].z, raw[u].w);
-            }
-            // the rows that were not requested ahead: batches of 8 requests (rolled loop)
-            constexpr int LB = 8;
-#pragma unroll 1
-            for (int ub = NPRE; ub < NROWS; ub += LB) {
-                float4 late[LB];
-#pragma unroll
-                for (int u = 0; u < LB; u++) {
-                    const int row = r0 + (ub + u) * RSTEP;
-                    late[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row < p.channels)
-                        late[u] = *(const float4 *)((const float2 *)p.vis +
-                                                    (size_t)row * p.vis_stride + bl);
-                }
-#pragma unroll
-                for (int u = 0; u < LB; u++) {
-                    const int row = r0 + (ub + u) * RSTEP;
-                    if (row < p.channels) {
-                        const int slot = LY::amp_slot(row);
-                        lds[(2 * q) * LY::ROW + slot] = ksp_abs_c64(late[u].x, late[u].y);
-                        lds[(2 * q + 1) * LY::ROW + slot] = ksp_abs_c64(late[u].z, late[u].w);
-                    }
-                }
-            }
-            return;
-        }
-        // amplitude input, or the ragged last strip: plain loads, no pipelining
-#pragma unroll 1
-        for (int row = r0; row < p.channels; row += RSTEP) {
+        for (int u = 0; u < LB; u++) {
+            const int row = rbase + u * RSTEP;
+            if (row >= C) break;
             float a0 = __builtin_nanf(""), a1 = __builtin_nanf("");
-            if (p.is_amplitude) {
+            if (plain) {
+                a0 = amp_with_flags(p, raw[u].x, raw[u].y, row, bl);
+                a1 = amp_with_flags(p, raw[u].z, raw[u].w, row, bl + 1);
+            } else if (p.is_amplitude) {
                 const float *src = (const float *)p.vis + (size_t)row * p.vis_stride + bl;
                 if (ok0) a0 = src[0];
                 if (ok1) a1 = src[1];
+                if (p.flags_mode == KSP_FLAGS_CHANNEL) {
+                    if (p.in_flags[row]) a0 = a1 = __builtin_nanf("");
+                } else if (p.flags_mode == KSP_FLAGS_FULL) {
+                    const uint8_t *f = p.in_flags + (size_t)row * p.in_flags_stride + bl;
+                    if (ok0 && f[0]) a0 = __builtin_nanf("");
+                    if (ok1 && f[1]) a1 = __builtin_nanf("");
+                }
             } else if (ok0) {
                 const float2 v = ((const float2 *)p.vis)[(size_t)row * p.vis_stride + bl];
-                a0 = ksp_abs_c64(v.x, v.y);
+                a0 = amp_with_flags(p, v.x, v.y, row, bl);
             }
-            const int slot = LY::amp_slot(row);
-            lds[(2 * q) * LY::ROW + slot] = a0;
-            lds[(2 * q + 1) * LY::ROW + slot] = a1;
+            const int idx = LY::index(row);
+            lds[(2 * q) * LY::ROW + idx] = a0;
+            lds[(2 * q + 1) * LY::ROW + idx] = a1;
+        }
+    };
+    constexpr int BATCH = RSTEP * LB;
+    float4 bufa[LB], bufb[LB];
+    request(bufa, r0);
+    for (int rbase = r0; rbase < C; rbase += 2 * BATCH) {
+        if (rbase + BATCH < C) request(bufb, rbase + BATCH);
+        finish(bufa, rbase);
+        if (rbase + BATCH < C) {
+            if (rbase + 2 * BATCH < C) request(bufa, rbase + 2 * BATCH);
+            finish(bufb, rbase + BATCH);
         }
     }
-};
+}
 
 // ---------------------------------------------------------------------------------
-// Median phase. Lane l slides the sorted window (median_window.h) over its run of R
-// channels of the wavefront's baseline. The loop is ROLLED in blocks of WIDTH steps
-// (the ring of the last WIDTH samples then keeps static register indices), which keeps
-// the code small enough for the instruction cache; amplitudes come from LDS by dynamic
-// address, and each deviation -- computed in float64 as the host does, then rounded to
-// float32 -- is stored back to LDS over an amplitude that is no longer needed
-// (FusedLayout::dev_slot). Rounding is monotone, so order statistics can be located on
-// the float32 values; the few samples whose exact value decides a result are
-// recomputed in float64 on demand (exact_dev). Returns the exact largest deviation of
-// the lane's run.
-template <int R, int WIDTH>
-__device__ __forceinline__ double median_phase(const FusedParams &p, int bl, float *myrow,
-                                             int lane, int C)
+// Median phase: lane l slides the sorted window over its run of R channels of the
+// wavefront's baseline. The deviation of every channel is computed in float64 (host
+// numerics) and kept ROUNDED TO FLOAT32 in registers -- 64 registers per lane instead
+// of 128 -- together with the exact largest deviation. Rounding is monotone, so order
+// statistics can be located on the float32 values; the few samples whose exact value
+// decides a result are recomputed in float64 on demand (exact_dev below).
+// `per_step(j)` is called once per output channel and lets the pipelined kernel
+// interleave the next strip's loads.
+template <int R, int WIDTH, class PerStep>
+__device__ __forceinline__ void median_phase(const float *myrow, int lane, int C, float (&dev)[R],
+                                             double &dmax, PerStep &&per_step)
 {
     using LY = FusedLayout<R>;
     constexpr int H = WIDTH / 2;
-    constexpr int STEPS = R + 2 * H;  // samples entering the window
-    constexpr int BLOCKS = (STEPS + WIDTH - 1) / WIDTH;
     const int c0 = lane * R;
-    double dmax = -__builtin_inf();
+    auto amp_at = [&](int c) -> float {
+        return (c >= 0 && c < C) ? myrow[LY::index(c)] : __builtin_nanf("");
+    };
+    dmax = -__builtin_inf();
     MedianWindow<WIDTH> win;
     win.reset();
     float ring[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) ring[i] = __builtin_nanf("");
-#pragma unroll 1
-    for (int blk = 0; blk < BLOCKS; blk++) {
+    // warm-up: samples c0-H .. c0+H-1 (ring slots 0 .. 2H-1)
 #pragma unroll
-        for (int k = 0; k < WIDTH; k++) {
-            const int t = blk * WIDTH + k;  // step: sample c0 - H + t enters
-            const int c_in = c0 - H + t;
-            float a_in = __builtin_nanf("");
-            if (t < STEPS && c_in >= 0 && c_in < C) {
-                a_in = myrow[LY::amp_slot(c_in)];
-                // input flags mask the sample (any non-zero value; host.py:143)
-                if (p.flags_mode == KSP_FLAGS_CHANNEL) {
-                    if (p.in_flags[c_in]) a_in = __builtin_nanf("");
-                } else if (p.flags_mode == KSP_FLAGS_FULL) {
-                    if (bl < p.baselines && p.in_flags[(size_t)c_in * p.in_flags_stride + bl])
-                        a_in = __builtin_nanf("");
-                }
-            }
-            win.step(ring[k], a_in);
-            ring[k] = a_in;
-            const int j = t - 2 * H;  // output channel offset within the run
-            if (j >= 0 && j < R) {    // wave-uniform
-                const float xc = ring[(k + WIDTH - H) % WIDTH];  // centre sample c0 + j
-                double d = 0.0;
-                if (xc == xc) d = (double)xc - win.median();
-                dmax = fmax(dmax, d);
-                myrow[lane * LY::RUN + (j < 6 ? R + j : j)] = (float)d;
-            }
-        }
+    for (int k = 0; k < 2 * H; k++) {
+        const float a = amp_at(c0 - H + k);
+        win.step(ring[k % WIDTH], a);
+        ring[k % WIDTH] = a;
     }
-    return dmax;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        per_step(j);
+        const int k = 2 * H + j;  // step number; the entering sample is channel c0 + H + j
+        const float a = (j + H < R) ? myrow[lane * LY::RUN + j + H] : amp_at(c0 + H + j);
+        const float a_in = (c0 + H + j < C) ? a : __builtin_nanf("");
+        win.step(ring[k % WIDTH], a_in);
+        ring[k % WIDTH] = a_in;
+        const float xc = ring[(k + WIDTH - H) % WIDTH];  // centre sample: channel c0 + j
+        double d = 0.0;
+        if (xc == xc) d = (double)xc - win.median();
+        dmax = fmax(dmax, d);
+        dev[j] = (float)d;
+    }
 }
 
-// ---------------------------------------------------------------------------------
-// Exact float64 deviation of a channel, recomputed from the float32 amplitudes of its
-// window (NaN = masked or outside the band). Same arithmetic as MedianWindow::median():
-// median of the valid samples, even counts averaged in float64. The amplitudes in LDS
-// have been overwritten by then, so the visibilities are read again (13 8-byte reads
-// per sample, served by L2 / Infinity Cache). Only the handful of samples that decide
-// a result come here.
-template <int WIDTH>
-__device__ __forceinline__ double exact_dev(const FusedParams &p, int bl, int c)
+// Exact float64 deviation of channel c, recomputed from the amplitudes of its window
+// (fetch(c) returns the float32 amplitude, NaN if the sample is masked or outside the
+// band). Same arithmetic as MedianWindow::median(): median of the valid samples, even
+// counts averaged in float64. Used only for the handful of samples that decide a
+// result, so it favours simplicity: invalid -> +inf, odd-even transposition sort.
+template <int WIDTH, class Fetch>
+__device__ __forceinline__ double exact_dev(int c, Fetch &&fetch)
 {
     constexpr int H = WIDTH / 2;
-    const int C = p.channels;
     float v[WIDTH];
-    float centre = __builtin_nanf("");
     int n = 0;
 #pragma unroll
     for (int k = 0; k < WIDTH; k++) {
-        const int cc = c - H + k;
-        float a = __builtin_nanf("");
-        if (cc >= 0 && cc < C && bl < p.baselines) {
-            if (p.is_amplitude) {
-                a = ((const float *)p.vis)[(size_t)cc * p.vis_stride + bl];
-                if (p.flags_mode == KSP_FLAGS_CHANNEL && p.in_flags[cc]) a = __builtin_nanf("");
-                if (p.flags_mode == KSP_FLAGS_FULL && p.in_flags[(size_t)cc * p.in_flags_stride + bl])
-                    a = __builtin_nanf("");
-            } else {
-                const float2 z = ((const float2 *)p.vis)[(size_t)cc * p.vis_stride + bl];
-                a = amp_with_flags(p, z.x, z.y, cc, bl);
-            }
-        }
-        if (k == H) centre = a;
+        const float a = fetch(c - H + k);
         const bool ok = a == a;
         n += ok;
         v[k] = ok ? a : __builtin_inff();
     }
-    // odd-even transposition sort (small code; invalid samples, +inf, end up last)
+    const float centre = fetch(c);
 #pragma unroll
     for (int round = 0; round < WIDTH; round++) {
 #pragma unroll
@@ -310,6 +236,13 @@ __device__ __forceinline__ int wave_sum_small(int c)
     return total;
 }
 
+__device__ __forceinline__ int wave_max_int(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 // Number of keys (over the whole wavefront) strictly below T, 1 <= T <= 32768. Two keys
 // per register: (key - T) has bit 15 set exactly when key < T because both are below
 // 2^15, so three packed 16-bit operations handle two samples.
@@ -331,67 +264,64 @@ __device__ __forceinline__ int count_less16(const unsigned (&kp)[NP], unsigned T
     return wave_sum_small<8>((int)acc.x + (int)acc.y);
 }
 
-// Exact |deviation| of every sample whose bit is set in `cand` (bit j <-> channel
-// c0 + j of this lane) -> list[0..n), at most `cap` entries; returns n (wave-uniform).
-// The candidates' channel numbers are first compacted into the list area (as ints),
-// then redistributed one per lane, so that the memory-bound recomputation runs once per
-// 64 candidates instead of once per candidate of the busiest lane.
-template <int WIDTH>
-__device__ __forceinline__ int gather_exact(const FusedParams &p, int bl, unsigned long long cand,
-                                            int c0, double *list, int cap, int lane)
+// Append the exact |deviation| of every sample whose bit is set in `cand` (bit j <->
+// channel c0 + j of this lane) to `list`, at most `cap` entries; returns the new
+// length (wave-uniform). All lanes stay active so that ballots see every lane.
+template <int WIDTH, class Fetch>
+__device__ __forceinline__ int gather_exact(unsigned long long cand, int c0, double *list,
+                                            int base, int cap, Fetch &&fetch)
 {
-    int *chan = (int *)(list + cap);
-    int n = 0;
     while (__any(cand != 0)) {
         const bool has = cand != 0;
         const int j = has ? __ffsll((long long)cand) - 1 : 0;
         cand &= cand - 1;
+        const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
         const unsigned long long m = __ballot(has);
-        const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (has && pos < cap) chan[pos] = c0 + j;
-        n += __popcll(m);
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (has && pos < cap) list[pos] = x;
+        base += __popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int m = min(n, cap);
-#pragma unroll 1
-    for (int base = 0; base < m; base += 64) {
-        const int i = base + lane;
-        const int c = i < m ? chan[i] : 0;
-        const double x = fabs(exact_dev<WIDTH>(p, bl, c));
-        if (i < m) list[i] = x;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    return n;
+    return base;
 }
 
-// Values of (stable) rank r and r - 1 among list[0..n).
+// Values of (stable) rank r and r - 1 among list[0..n): each lane ranks the entries
+// ci = lane, lane + 64, ... against all others.
 __device__ __forceinline__ void rank_in_list(const double *list, int n, int r, int lane,
                                              double &xk, double &prev, bool &have_prev)
 {
     xk = 0.0;
     prev = 0.0;
     have_prev = false;
-#pragma unroll 1
+    if (n <= 64) {
+        // one candidate per lane; the others arrive by lane broadcast (v_readlane)
+        const bool live = lane < n;
+        const double x = live ? list[lane] : 0.0;
+        const int xlo = __double2loint(x), xhi = __double2hiint(x);
+        int cnt = 0;
+        for (int jj = 0; jj < n; jj++) {
+            const double y = __hiloint2double(__builtin_amdgcn_readlane(xhi, jj),
+                                              __builtin_amdgcn_readlane(xlo, jj));
+            cnt += (y < x) || (y == x && jj < lane);
+        }
+        const unsigned long long hit = __ballot(live && cnt == r);
+        const unsigned long long hitp = __ballot(live && cnt == r - 1);
+        xk = __shfl(x, __ffsll((long long)hit) - 1, 64);
+        if (hitp) {
+            prev = __shfl(x, __ffsll((long long)hitp) - 1, 64);
+            have_prev = true;
+        }
+        return;
+    }
     for (int ci = lane; ci < ((n + 63) & ~63); ci += 64) {
         const bool live = ci < n;
         const double x = live ? list[ci] : 0.0;
         int cnt = 0;
-        if (n <= 64) {
-            // one candidate per lane; the others arrive by lane broadcast (v_readlane)
-            const int xlo = __double2loint(x), xhi = __double2hiint(x);
-            for (int jj = 0; jj < n; jj++) {
-                const double y = __hiloint2double(__builtin_amdgcn_readlane(xhi, jj),
-                                                  __builtin_amdgcn_readlane(xlo, jj));
-                cnt += (y < x) || (y == x && jj < ci);
-            }
-        } else {
-            for (int jj = 0; jj < n; jj++) {
-                const double y = list[jj];
-                cnt += (y < x) || (y == x && jj < ci);
-            }
+        for (int jj = 0; jj < n; jj++) {
+            const double y = list[jj];
+            cnt += (y < x) || (y == x && jj < ci);
         }
         const unsigned long long hit = __ballot(live && cnt == r);
         const unsigned long long hitp = __ballot(live && cnt == r - 1);
@@ -403,17 +333,14 @@ __device__ __forceinline__ void rank_in_list(const double *list, int n, int r, i
     }
 }
 
-// Returns the float64 noise estimate (NaN when every deviation is zero). `myrow` holds
-// the float32 deviations (dev_slot layout); `list` is this wavefront's candidate list.
-template <int R, int WIDTH, int LIST_CAP>
-__device__ __forceinline__ double mad_noise(const FusedParams &p, int bl, const float *myrow,
-                                            int lane, double *list)
+// `list` is this wavefront's private candidate list in LDS (LIST_CAP doubles).
+// Returns the float64 noise estimate (NaN when every deviation is zero).
+template <int R, int WIDTH, int LIST_CAP, class Fetch>
+__device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, double *list,
+                                            Fetch &&fetch)
 {
-    using LY = FusedLayout<R>;
     constexpr int NP = R / 2;
     const int c0 = lane * R;
-    const float *mydev = myrow + lane * LY::RUN;
-    auto dev_at = [&](int j) -> float { return mydev[j < 6 ? R + j : j]; };
     // 1. 15-bit keys = float32 exponent + 7 mantissa bits of |dev|, two per register.
     //    float32(|d|) is monotone in |d| and so is its truncation, hence the key bin of
     //    the median can be found without knowing any exact value.
@@ -421,9 +348,9 @@ __device__ __forceinline__ double mad_noise(const FusedParams &p, int bl, const 
     int zeros = 0;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        const float d0 = dev_at(2 * i), d1 = dev_at(2 * i + 1);
-        zeros += (d0 == 0.0f) + (d1 == 0.0f);
-        kp[i] = ((__float_as_uint(d0) >> 16) & 0x7fffu) | (__float_as_uint(d1) & 0x7fff0000u);
+        zeros += (dev[2 * i] == 0.0f) + (dev[2 * i + 1] == 0.0f);
+        kp[i] = ((__float_as_uint(dev[2 * i]) >> 16) & 0x7fffu) |
+                (__float_as_uint(dev[2 * i + 1]) & 0x7fff0000u);
     }
     zeros = wave_sum_small<8>(zeros);
     const int total = 64 * R;
@@ -434,7 +361,6 @@ __device__ __forceinline__ double mad_noise(const FusedParams &p, int bl, const 
     // 2. which key bin holds the median, and how many samples lie below the bin
     unsigned K = 0;
     int below_bin = 0;
-#pragma unroll 1
     for (int bit = 14; bit >= 0; bit--) {
         const unsigned test = K | (1u << bit);
         const int c = count_less16<NP>(kp, test);
@@ -446,25 +372,27 @@ __device__ __forceinline__ double mad_noise(const FusedParams &p, int bl, const 
     auto key_of = [&](int j) -> unsigned {
         return (j & 1) ? (kp[j / 2] >> 16) : (kp[j / 2] & 0xffffu);
     };
+    auto bin_mask = [&](unsigned key) -> unsigned long long {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (key_of(j) == key) m |= 1ull << j;
+        return m;
+    };
     int in_bin = count_less16<NP>(kp, K + 1) - below_bin;
     int r = rank - below_bin;  // 0-based rank inside the bin
-    unsigned long long cand = 0;
-#pragma unroll
-    for (int j = 0; j < R; j++)
-        if (key_of(j) == K) cand |= 1ull << j;
-    unsigned cur32 = 0;  // set when the bin had to be narrowed to one float32 value
+    unsigned long long cand = bin_mask(K);
     if (in_bin > LIST_CAP) {
-        // Degenerate data (many samples in one key bin, e.g. quantised input): narrow
-        // the bin with an exact search on the full float32 patterns, which leaves only
-        // samples whose float32 deviations are identical.
+        // Degenerate data (hundreds of samples in one key bin, e.g. quantised input):
+        // narrow the bin with an exact search on the full float32 patterns, which
+        // leaves only samples whose float32 deviations are identical.
         unsigned cur = K << 16;
         int below = below_bin;
-#pragma unroll 1
         for (int bit = 15; bit >= 0; bit--) {
             const unsigned test = cur | (1u << bit);
             int c = 0;
-#pragma unroll 1
-            for (int j = 0; j < R; j++) c += (__float_as_uint(dev_at(j)) & 0x7fffffffu) < test;
+#pragma unroll
+            for (int j = 0; j < R; j++) c += (__float_as_uint(dev[j]) & 0x7fffffffu) < test;
             c = ksp_wave_sum(c);
             if (c <= rank) {
                 cur = test;
@@ -472,58 +400,83 @@ __device__ __forceinline__ double mad_noise(const FusedParams &p, int bl, const 
             }
         }
         cand = 0;
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < R; j++)
-            if ((__float_as_uint(dev_at(j)) & 0x7fffffffu) == cur) cand |= 1ull << j;
+            if ((__float_as_uint(dev[j]) & 0x7fffffffu) == cur) cand |= 1ull << j;
         in_bin = ksp_wave_sum(__popcll(cand));
         r = rank - below;
         below_bin = below;
-        cur32 = cur;
-    }
-    // 3. recompute the bin's (few) samples exactly and rank them in float64; if the
-    //    lower median (even counts) lies below the bin, a second pass does the same for
-    //    the largest float32 values below it. One loop = one inlined copy of the
-    //    recomputation.
-    double xk = 0.0, prev = 0.0;
-    bool have_prev = false;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        if (pass == 1) {
-            if (!even || have_prev) break;
-            // largest float32 magnitude strictly below the selected bin/value
-            float b32 = 0.0f;
-#pragma unroll 1
-            for (int j = 0; j < R; j++) {
-                const float a = fabsf(dev_at(j));
-                const bool lower = cur32 ? (__float_as_uint(a) < cur32)
-                                         : (((__float_as_uint(a) >> 16) & 0x7fffu) < K);
-                b32 = lower ? fmaxf(b32, a) : b32;
+        if (in_bin > LIST_CAP) {
+            // still too many: they share one float32 value. If their exact values are
+            // all equal (the usual reason), that value is the answer for rank r and
+            // r - 1 alike; otherwise give the float32 value (documented limitation).
+            double lo = __builtin_inf(), hi = 0.0;
+            unsigned long long todo = cand;
+            while (__any(todo != 0)) {
+                const bool has = todo != 0;
+                const int j = has ? __ffsll((long long)todo) - 1 : 0;
+                todo &= todo - 1;
+                const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
+                lo = has ? fmin(lo, x) : lo;
+                hi = has ? fmax(hi, x) : hi;
             }
-            b32 = ksp_wave_max(b32);
-            cand = 0;
-#pragma unroll 1
-            for (int j = 0; j < R; j++)
-                if (fabsf(dev_at(j)) == b32) cand |= 1ull << j;
-        }
-        const int n = gather_exact<WIDTH>(p, bl, cand, c0, list, LIST_CAP, lane);
-        if (pass == 0) {
-            if (n > LIST_CAP) {
-                // more than LIST_CAP samples share ONE float32 deviation. Their exact
-                // values are taken to be that value (true for the quantised data that
-                // produces such ties; documented limitation otherwise).
-                xk = (double)__uint_as_float(cur32);
-                if (r > 0) {
-                    prev = xk;
-                    have_prev = true;
+            lo = ksp_wave_min(lo);
+            hi = ksp_wave_max(hi);
+            double xk = (lo == hi) ? lo : (double)__uint_as_float(cur);
+            if (even && r == 0) {
+                // lower median lies below this value: largest float32 value below it
+                float b32 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const float a = fabsf(dev[j]);
+                    b32 = (__float_as_uint(a) < cur) ? fmaxf(b32, a) : b32;
                 }
-            } else {
-                rank_in_list(list, n, r, lane, xk, prev, have_prev);
+                b32 = ksp_wave_max(b32);
+                unsigned long long bm = 0;
+#pragma unroll
+                for (int j = 0; j < R; j++)
+                    if (fabsf(dev[j]) == b32) bm |= 1ull << j;
+                const int n2 = gather_exact<WIDTH>(bm, c0, list, 0, LIST_CAP, fetch);
+                double below_max = 0.0;
+                for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
+                below_max = ksp_wave_max(below_max);
+                __builtin_amdgcn_wave_barrier();
+                xk = (xk + below_max) / 2.0;
             }
-        } else {
-            double below_max = 0.0;
-            for (int i = lane; i < min(n, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
-            prev = ksp_wave_max(below_max);
+            return xk * FUSED_MAD_NORMAL;
         }
+    }
+    // 3. recompute the bin's (few) samples exactly and rank them in float64
+    gather_exact<WIDTH>(cand, c0, list, 0, LIST_CAP, fetch);
+    double xk, prev;
+    bool have_prev;
+    rank_in_list(list, in_bin, r, lane, xk, prev, have_prev);
+    __builtin_amdgcn_wave_barrier();
+    if (even && !have_prev) {
+        // r == 0: the lower median is the largest value below the bin, i.e. the
+        // largest exact value of the highest non-empty bin below K
+        int k2 = -1;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int kj = (int)key_of(j);
+            k2 = (kj < (int)K) ? max(k2, kj) : k2;
+        }
+        k2 = wave_max_int(k2);
+        unsigned long long bm = bin_mask((unsigned)k2);
+        // within that bin the largest float32 values are enough
+        float b32 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if ((bm >> j) & 1) b32 = fmaxf(b32, fabsf(dev[j]));
+        b32 = ksp_wave_max(b32);
+        unsigned long long top = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (((bm >> j) & 1) && fabsf(dev[j]) == b32) top |= 1ull << j;
+        const int n2 = gather_exact<WIDTH>(top, c0, list, 0, LIST_CAP, fetch);
+        double below_max = 0.0;
+        for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
+        prev = ksp_wave_max(below_max);
         __builtin_amdgcn_wave_barrier();
     }
     if (even) xk = (xk + prev) / 2.0;  // float64 mean, as numpy.median
@@ -531,8 +484,7 @@ __device__ __forceinline__ double mad_noise(const FusedParams &p, int bl, const 
 }
 
 // ---------------------------------------------------------------------------------
-// Thresholds. Returns the flag mask of the lane's run (bit j: channel c0 + j). The
-// deviations in `myrow` are used as scratch when windows have to be summed.
+// Thresholds. Returns the flag mask of the lane's run (bit j: channel c0 + j).
 //
 // SumThreshold is evaluated on the float32 deviations with a rigorous error bound:
 // |float32(d) - d| <= 2^-24 |d|, so a window sum computed from the rounded values is
@@ -540,15 +492,14 @@ __device__ __forceinline__ double mad_noise(const FusedParams &p, int bl, const 
 // float64 sum. Windows whose sum is further than that from the limit are decided as
 // the exact arithmetic would decide them; the others (practically never) are summed
 // again from exact deviations.
-template <int R, int WIDTH>
-__device__ __forceinline__ unsigned long long threshold_flags(const FusedParams &p, int bl,
-                                                              float *myrow, double dmax,
-                                                              double noise64, int lane, int C)
+template <int R, int WIDTH, class Fetch>
+__device__ __forceinline__ unsigned long long threshold_flags(const FusedParams &p,
+                                                              const float (&dev)[R], double dmax,
+                                                              double noise64, int lane, int C,
+                                                              Fetch &&fetch)
 {
-    using LY = FusedLayout<R>;
     static_assert(R <= 64, "flag mask is 64 bits");
     const int c0 = lane * R;
-    float *mydev = myrow + lane * LY::RUN;
     unsigned long long fl = 0;
     if (p.threshold_kind == KSP_THRESHOLD_SIMPLE) {
         const double thr = p.n_sigma * noise64;  // float64 product (host.py:182)
@@ -556,9 +507,9 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
             // float32(d) > thr decides d > thr except when float32(d) is within one
             // rounding of thr; those samples are recomputed exactly
             unsigned long long unsure = 0;
-#pragma unroll 1
+#pragma unroll
             for (int j = 0; j < R; j++) {
-                const double d = (double)mydev[j < 6 ? R + j : j];
+                const double d = (double)dev[j];
                 const double slack = fabs(d) * 0x1p-23;
                 if (d - slack > thr)
                     fl |= 1ull << j;
@@ -569,21 +520,21 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
                 const bool has = unsure != 0;
                 const int j = has ? __ffsll((long long)unsure) - 1 : 0;
                 unsure &= unsure - 1;
-                const double d = exact_dev<WIDTH>(p, bl, c0 + j);
+                const double d = exact_dev<WIDTH>(c0 + j, fetch);
                 if (has && d > thr) fl |= 1ull << j;
             }
         }
         return fl;
     }
     const double t1 = p.n_sigma * noise64;  // host.py:252
-    // (static indices only: a runtime-indexed register array would live in scratch)
+    // (static indices only: a runtime-indexed array would live in scratch memory)
     constexpr int MAXW = 4;
     float thr[MAXW];
     float thr_min = __builtin_inff();
     bool thr_nan = false;
 #pragma unroll
     for (int k = 0; k < MAXW; k++) {
-        thr[k] = (float)(t1 * p.scales[k]);  // host.py:235
+        thr[k] = (float)(t1 * p.scales[k < KSP_MAX_WINDOWS ? k : 0]);  // host.py:235
         if (k < p.n_windows) {
             thr_min = fminf(thr_min, thr[k]);
             thr_nan |= (thr[k] != thr[k]);
@@ -595,44 +546,43 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
     const bool any = !(thr_min > 0.0f) || (dmax >= cand);
     if (thr_nan || !__any(any)) return 0;
 
-    // value of channel c of this baseline as the window sums see it (any lane's run)
-    auto dval = [&](int c) -> float { return myrow[LY::dev_slot(c)]; };
-#pragma unroll 1
-    for (int k = 0; k < p.n_windows; k++) {  // rolled: one copy of the window code
+    float d[R];  // working copy: deviations with flagged samples replaced by thr
+#pragma unroll
+    for (int j = 0; j < R; j++) d[j] = dev[j];
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) {
+        if (k >= p.n_windows) break;
         const int w = 1 << k;
-        const float thrf = k == 0 ? thr[0] : (k == 1 ? thr[1] : (k == 2 ? thr[2] : thr[3]));
+        const float thrf = thr[k];
         const double limit = (double)__fmul_rn(thrf, (float)w);  // host.py:242
-        // already-flagged samples contribute exactly thr (host.py:237; thr is a float32)
-        {
-            unsigned long long m = fl;
-            while (m) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                mydev[j < 6 ? R + j : j] = thrf;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // flag bits of the 7 channels after this run (substituted values are exact)
-        unsigned nfl = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if ((fl >> j) & 1) d[j] = thrf;  // host.py:237 (exact: thr is a float32)
+        // the next lanes' first 7 values and flag bits (w - 1 <= 7 are used)
+        float ext[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) ext[m] = __shfl_down(d[m % R], 1 + m / R, 64);
+        unsigned nfl = 0;  // flag bits of the 7 channels after this run
 #pragma unroll
         for (int m = 0; m < 7; m++) {
             const unsigned long long f = __shfl_down(fl, 1 + m / R, 64);
             nfl |= (unsigned)((f >> (m % R)) & 1) << m;
         }
         unsigned long long hits = 0, unsure = 0;
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < R; j++) {
-            const bool valid = (c0 + j + w <= C);
             double s = 0.0, mag = 0.0;
-#pragma unroll 1
+#pragma unroll
             for (int m = 0; m < w; m++) {
-                const int jj = j + m;
-                const bool sub = (jj < R) ? ((fl >> jj) & 1) : ((nfl >> (jj - R)) & 1);
-                const double v = valid ? (double)dval(c0 + jj) : 0.0;
-                s += v;
-                mag += sub ? 0.0 : fabs(v);
+                {
+                    const int jj = j + m;
+                    const float v = (jj < R) ? d[jj % R] : ext[(jj >= R) ? (jj - R) % 7 : 0];
+                    const bool sub = (jj < R) ? ((fl >> (jj % 64)) & 1) : ((nfl >> ((jj >= R) ? (jj - R) % 7 : 0)) & 1);
+                    s += (double)v;
+                    mag += sub ? 0.0 : fabs((double)v);  // substituted values are exact
+                }
             }
+            const bool valid = (c0 + j + w <= C);
             const double slack = mag * 0x1p-23;
             if (valid) {
                 if (s - slack > limit)
@@ -647,11 +597,10 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
             const int j = has ? __ffsll((long long)unsure) - 1 : 0;
             unsure &= unsure - 1;
             double s = 0.0;
-#pragma unroll 1
             for (int m = 0; m < w; m++) {
                 const int jj = j + m;
                 const bool sub = (jj < R) ? ((fl >> jj) & 1) : ((nfl >> (jj - R)) & 1);
-                const double x = exact_dev<WIDTH>(p, bl, c0 + jj);
+                const double x = exact_dev<WIDTH>(c0 + jj, fetch);
                 s += sub ? (double)thrf : x;
             }
             if (has && s > limit) hits |= 1ull << j;

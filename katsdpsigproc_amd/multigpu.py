@@ -16,8 +16,8 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-#: baselines per work unit of the fused kernel; shards are cut on this boundary so
-#: that no strip straddles two GPUs
+#: shard boundary in baselines: 64-byte row segments, and a multiple of the fused
+#: kernel's 4-baseline strip so that no strip straddles two GPUs
 STRIP = 8
 
 
