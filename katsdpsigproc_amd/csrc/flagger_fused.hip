@@ -52,28 +52,34 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         return (c >= 0 && c < C) ? myrow[LY::index(c)] : __builtin_nanf("");
     };
     float dev[R];
-    double dmax;
-    median_phase<R, WIDTH>(myrow, lane, C, dev, dmax, [](int) {});
-    if (p.debug_stop == 2) {
-        float acc = (float)dmax;
+    float dmax;
+    median_phase<R, WIDTH>(myrow, lane, dev, dmax);
+    // From here on the arguments are re-read from the kernarg segment (scalar loads):
+    // keeping some 30 argument registers alive across the median phase would starve
+    // it of the scalar registers its lane masks live in.
+    const FusedParams *args = (const FusedParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(args));
+    const FusedParams &pa = *args;
+    if (pa.debug_stop == 2) {
+        float acc = dmax;
 #pragma unroll
         for (int j = 0; j < R; j++) acc += dev[j];
-        if (acc == 12345.678f && p.noise) p.noise[0] = acc;  // keep the work alive
+        if (acc == 12345.678f && pa.noise) pa.noise[0] = acc;  // keep the work alive
         return;
     }
 
     const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch);
-    if (lane == 0 && p.noise != nullptr && bl < p.baselines) p.noise[bl] = (float)noise64;
-    if (p.debug_stop == 3) return;
+    if (lane == 0 && pa.noise != nullptr && bl < pa.baselines) pa.noise[bl] = (float)noise64;
+    if (pa.debug_stop == 3) return;
 
     const unsigned long long fl =
-        threshold_flags<R, WIDTH>(p, dev, dmax, noise64, lane, C, fetch);
-    if (p.debug_stop == 4) {
-        if (fl == 0x123456789abcull && p.noise) p.noise[0] = 1.0f;
+        threshold_flags<R, WIDTH>(pa, dev, dmax, noise64, lane, C, fetch);
+    if (pa.debug_stop == 4) {
+        if (fl == 0x123456789abcull && pa.noise) pa.noise[0] = 1.0f;
         return;
     }
 
-    if (p.deviations != nullptr) {
+    if (pa.deviations != nullptr) {
         // stage float32 deviations in this wavefront's LDS row (the amplitudes are no
         // longer needed), then write them as [channel][8 baselines]
 #pragma unroll
@@ -86,16 +92,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
             const int idx = LY::index(row);
             const float v0 = lds[(2 * q) * LY::ROW + idx];
             const float v1 = lds[(2 * q + 1) * LY::ROW + idx];
-            float *dst = p.deviations + (size_t)row * p.dev_stride + blq;
-            if (blq + 1 < p.baselines && (p.dev_stride & 1) == 0)
+            float *dst = pa.deviations + (size_t)row * pa.dev_stride + blq;
+            if (blq + 1 < pa.baselines && (pa.dev_stride & 1) == 0)
                 *(float2 *)dst = make_float2(v0, v1);
             else {
-                if (blq < p.baselines) dst[0] = v0;
-                if (blq + 1 < p.baselines) dst[1] = v1;
+                if (blq < pa.baselines) dst[0] = v0;
+                if (blq + 1 < pa.baselines) dst[1] = v1;
             }
         }
     }
-    write_flags(p, fl, lane * R, bl, C);
+    write_flags(pa, fl, lane * R, bl, C);
 }
 
 // =================================================================================

@@ -132,53 +132,70 @@ __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int
             finish(bufb, rbase + BATCH);
         }
     }
+    // channels C .. 64 R - 1 do not exist; the median phase expects NaN there
+    for (int row = C + r0; row < 64 * R; row += RSTEP) {
+        const int idx = LY::index(row);
+        lds[(2 * q) * LY::ROW + idx] = __builtin_nanf("");
+        lds[(2 * q + 1) * LY::ROW + idx] = __builtin_nanf("");
+    }
 }
 
 // ---------------------------------------------------------------------------------
 // Median phase: lane l slides the sorted window over its run of R channels of the
-// wavefront's baseline. The deviation of every channel is computed in float64 (host
-// numerics) and kept ROUNDED TO FLOAT32 in registers -- 64 registers per lane instead
-// of 128 -- together with the exact largest deviation. Rounding is monotone, so order
-// statistics can be located on the float32 values; the few samples whose exact value
-// decides a result are recomputed in float64 on demand (exact_dev below).
-// `per_step(j)` is called once per output channel and lets the pipelined kernel
-// interleave the next strip's loads.
-template <int R, int WIDTH, class PerStep>
-__device__ __forceinline__ void median_phase(const float *myrow, int lane, int C, float (&dev)[R],
-                                             double &dmax, PerStep &&per_step)
+// wavefront's baseline. Deviations are kept ROUNDED TO FLOAT32 in registers -- 64
+// registers per lane instead of 128 -- together with their maximum. Rounding is
+// monotone, so order statistics can be located on the float32 values; the few samples
+// whose exact float64 value decides a result are recomputed on demand (exact_dev).
+// The LDS row holds NaN for every sample that must not take part (flagged, NaN input,
+// channels >= C); channels outside [0, 64 R) are never read.
+template <int R, int WIDTH>
+__device__ __forceinline__ void median_phase(const float *myrow, int lane, float (&dev)[R],
+                                             float &dmax)
 {
     using LY = FusedLayout<R>;
     constexpr int H = WIDTH / 2;
-    const int c0 = lane * R;
-    auto amp_at = [&](int c) -> float {
-        return (c >= 0 && c < C) ? myrow[LY::index(c)] : __builtin_nanf("");
+    const float *run = myrow + lane * LY::RUN;
+    const float nan = __builtin_nanf("");
+    // amplitude of channel lane*R + i, -H <= i < R + H. When the window reaches no
+    // further than the neighbouring lanes' runs, which sit RUN = R + 4 words away,
+    // every address is `run` plus a constant.
+    auto amp_rel = [&](int i) -> float {
+        if (i >= 0 && i < R) return run[i];
+        if constexpr (H <= R) {
+            if (i < 0) return lane > 0 ? run[i - (LY::RUN - R)] : nan;
+            return lane < 63 ? run[i + (LY::RUN - R)] : nan;
+        } else {
+            const int c = lane * R + i;
+            return (c >= 0 && c < 64 * R) ? myrow[LY::index(c)] : nan;
+        }
     };
-    dmax = -__builtin_inf();
-    MedianWindow<WIDTH> win;
+    dmax = -__builtin_inff();
+    SortedWindow<WIDTH> win;
     win.reset();
+    // the last WIDTH samples (NaN = takes no part). Whether a sample takes part is
+    // re-derived from its value when it leaves and when it is the centre: a compare
+    // each, where remembering the lane masks would tie up 26 scalar registers.
     float ring[WIDTH];
 #pragma unroll
-    for (int i = 0; i < WIDTH; i++) ring[i] = __builtin_nanf("");
-    // warm-up: samples c0-H .. c0+H-1 (ring slots 0 .. 2H-1)
-#pragma unroll
-    for (int k = 0; k < 2 * H; k++) {
-        const float a = amp_at(c0 - H + k);
-        win.step(ring[k % WIDTH], a);
+    for (int j = -2 * H; j < R; j++) {
+        const int k = 2 * H + j;  // step number; channel (relative) H + j enters
+        const float a = amp_rel(H + j);
+        if (k < WIDTH) {
+            win.step_pad_out(a, a == a);  // what leaves is still the reset padding
+        } else {
+            float out = ring[k % WIDTH];
+            asm("" : "+v"(out));  // opaque: do not carry the entry-time mask along
+            win.step(out, out == out, a, a == a);
+        }
         ring[k % WIDTH] = a;
-    }
-#pragma unroll
-    for (int j = 0; j < R; j++) {
-        per_step(j);
-        const int k = 2 * H + j;  // step number; the entering sample is channel c0 + H + j
-        const float a = (j + H < R) ? myrow[lane * LY::RUN + j + H] : amp_at(c0 + H + j);
-        const float a_in = (c0 + H + j < C) ? a : __builtin_nanf("");
-        win.step(ring[k % WIDTH], a_in);
-        ring[k % WIDTH] = a_in;
-        const float xc = ring[(k + WIDTH - H) % WIDTH];  // centre sample: channel c0 + j
-        double d = 0.0;
-        if (xc == xc) d = (double)xc - win.median();
-        dmax = fmax(dmax, d);
-        dev[j] = (float)d;
+        if (j >= 0) {
+            float xc = ring[(k + WIDTH - H) % WIDTH];  // centre: relative channel j
+            asm("" : "+v"(xc));
+            float d = win.deviation(xc);
+            d = (xc == xc) ? d : 0.0f;
+            dmax = __builtin_amdgcn_fmed3f(dmax, d, win.pinf);  // max, no canonicalise
+            dev[j] = d;
+        }
     }
 }
 
@@ -494,7 +511,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
 // again from exact deviations.
 template <int R, int WIDTH, class Fetch>
 __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams &p,
-                                                              const float (&dev)[R], double dmax,
+                                                              const float (&dev)[R], float dmax,
                                                               double noise64, int lane, int C,
                                                               Fetch &&fetch)
 {
@@ -503,7 +520,8 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
     unsigned long long fl = 0;
     if (p.threshold_kind == KSP_THRESHOLD_SIMPLE) {
         const double thr = p.n_sigma * noise64;  // float64 product (host.py:182)
-        if (__any(dmax > thr)) {
+        // dmax is the largest ROUNDED deviation: exact d <= dmax (1 + 2^-24)
+        if (__any((double)dmax * (1.0 + 0x1p-23) > thr)) {
             // float32(d) > thr decides d > thr except when float32(d) is within one
             // rounding of thr; those samples are recomputed exactly
             unsigned long long unsure = 0;
@@ -543,7 +561,7 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
     // Fast reject (exact): no window can fire unless some sample reaches
     // min_k thr_k; the 2^-20 margin makes the test conservative; needs thresholds > 0.
     const double cand = (double)thr_min * (1.0 - 0x1p-20);
-    const bool any = !(thr_min > 0.0f) || (dmax >= cand);
+    const bool any = !(thr_min > 0.0f) || ((double)dmax >= cand);
     if (thr_nan || !__any(any)) return 0;
 
     float d[R];  // working copy: deviations with flagged samples replaced by thr

@@ -51,6 +51,15 @@ __device__ __forceinline__ float ksp_abs_c64(float re, float im)
 }
 
 // Wave-wide (64-lane) reductions with every lane receiving the result.
+// Wavefront vote as a scalar mask: v_cmp writes the lane mask straight into a scalar
+// register pair, so "any lane" is one scalar compare (HIP's __any/__ballot go through
+// a v_cndmask/v_cmp pair first).
+__device__ __forceinline__ unsigned long long ksp_ballot(bool x)
+{
+    return __builtin_amdgcn_ballot_w64(x);
+}
+__device__ __forceinline__ bool ksp_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
+
 __device__ __forceinline__ int ksp_wave_sum(int v)
 {
 #pragma unroll

@@ -71,3 +71,87 @@ struct MedianWindow {
         return (n_pos == n_neg) ? hi : (lo + hi) * 0.5;
     }
 };
+
+// ---------------------------------------------------------------------------------
+// Same sorted window, with the padding bookkeeping reduced to ONE boolean per lane.
+// The invariant 0 <= #(+inf) - #(-inf) <= 1 means the two counters of MedianWindow
+// carry a single bit of state: `odd` = "one more +inf than -inf" (equivalently: the
+// number of valid samples is even). A lane-boolean lives in a scalar register pair as
+// a wavefront mask, so updating it is scalar-unit work and the vector unit only runs
+// the compares/selects of the sorted array itself. The caller supplies, next to each
+// leaving/entering sample, whether it is padding (flagged, NaN or out of band).
+template <int WIDTH>
+struct SortedWindow {
+    static constexpr int H = WIDTH / 2;
+    float s[WIDTH];  // sorted ascending
+    bool odd;        // #(+inf paddings) == #(-inf paddings) + 1
+    float pinf, ninf;  // +-infinity, opaque to the optimiser (see reset)
+
+    __device__ __forceinline__ void reset()
+    {
+        // Kept opaque so that med3(a, b, +-inf) stays ONE v_med3_f32: folded to
+        // fminf/fmaxf it would drag a NaN-canonicalising v_max_f32 x, x, x along.
+        pinf = __builtin_inff();
+        ninf = -__builtin_inff();
+        asm volatile("" : "+v"(pinf), "+v"(ninf));
+#pragma unroll
+        for (int i = 0; i < WIDTH; i++) s[i] = i < H ? ninf : pinf;
+        odd = true;
+    }
+
+    // `in_ok`: the entering sample takes part (otherwise its value is ignored and a
+    // padding enters on the side that keeps the balance)
+    __device__ __forceinline__ void insert(const float (&L)[WIDTH - 1], float in, bool in_ok)
+    {
+        const float vi = in_ok ? in : (odd ? ninf : pinf);
+        odd = (odd == in_ok);  // toggles when a padding entered
+        s[0] = __builtin_amdgcn_fmed3f(L[0], vi, ninf);  // min
+#pragma unroll
+        for (int i = 1; i < WIDTH - 1; i++) s[i] = __builtin_amdgcn_fmed3f(L[i - 1], vi, L[i]);
+        s[WIDTH - 1] = __builtin_amdgcn_fmed3f(L[WIDTH - 2], vi, pinf);  // max
+    }
+
+    // Replace a leaving PADDING (statically known, e.g. the reset state during warm-up)
+    // by `in`: +inf paddings sit at the top, -inf paddings at the bottom, so removal
+    // is a shift selected by `odd` -- no compares.
+    __device__ __forceinline__ void step_pad_out(float in, bool in_ok)
+    {
+        float L[WIDTH - 1];
+#pragma unroll
+        for (int i = 0; i < WIDTH - 1; i++) L[i] = odd ? s[i] : s[i + 1];
+        odd = !odd;
+        insert(L, in, in_ok);
+    }
+
+    // Replace `out` by `in`; *_ok tell whether the sample takes part (a padding's
+    // value is ignored).
+    __device__ __forceinline__ void step(float out, bool out_ok, float in, bool in_ok)
+    {
+        // a leaving padding is taken from the +inf side when that side is ahead
+        const float vo = out_ok ? out : (odd ? pinf : ninf);
+        odd = (odd == out_ok);
+        float L[WIDTH - 1];
+#pragma unroll
+        for (int i = 0; i < WIDTH - 1; i++) L[i] = (s[i] < vo) ? s[i] : s[i + 1];
+        insert(L, in, in_ok);
+    }
+
+    // float32(centre - median of the valid samples), the median and the subtraction
+    // evaluated in float64 as the host path does. With an odd number of valid samples
+    // the median is the float32 s[H] and float32(double(x) - double(m)) equals the
+    // float32 difference x - m (the double difference is exact or differs from the
+    // larger operand by far less than half a float32 ulp), so one v_sub_f32 suffices;
+    // the float64 mean is only needed by lanes with an even count, and the whole
+    // wavefront skips it when no lane has one.
+    __device__ __forceinline__ float deviation(float x) const
+    {
+        float d = x - s[H];
+        if (odd) {
+            // the empty asm keeps this a real branch (skipped when no lane is odd)
+            // instead of eight speculated float64 instructions per step
+            asm volatile("");
+            d = (float)((double)x - ((double)s[H > 0 ? H - 1 : 0] + (double)s[H]) * 0.5);
+        }
+        return d;
+    }
+};
