@@ -68,9 +68,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         return;
     }
 
-    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch);
+    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, pa.debug_stop);
     if (lane == 0 && pa.noise != nullptr && bl < pa.baselines) pa.noise[bl] = (float)noise64;
-    if (pa.debug_stop == 3) return;
+    if (pa.debug_stop == 3 || pa.debug_stop > 30) return;
 
     const unsigned long long fl =
         threshold_flags<R, WIDTH>(pa, dev, dmax, noise64, lane, C, fetch);

@@ -260,25 +260,58 @@ __device__ __forceinline__ int wave_max_int(int v)
     return v;
 }
 
-// Number of keys (over the whole wavefront) strictly below T, 1 <= T <= 32768. Two keys
-// per register: (key - T) has bit 15 set exactly when key < T because both are below
-// 2^15, so three packed 16-bit operations handle two samples.
+// 32 x 32 bit-matrix transpose in registers: afterwards a[c] bit i = (old a[i]) bit c.
+// The two coarse stages move whole bytes (v_perm_b32), the three fine ones are the
+// classic masked-swap butterflies.
+__device__ __forceinline__ void transpose_bits32(unsigned (&a)[32])
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const unsigned x = a[k], y = a[k + 16];
+        a[k] = __builtin_amdgcn_perm(y, x, 0x05040100u);
+        a[k + 16] = __builtin_amdgcn_perm(y, x, 0x07060302u);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if (k & 8) continue;
+        const unsigned x = a[k], y = a[k | 8];
+        a[k] = __builtin_amdgcn_perm(y, x, 0x06020400u);
+        a[k | 8] = __builtin_amdgcn_perm(y, x, 0x07030501u);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int j = 4 >> s;
+        const unsigned m = s == 0 ? 0x0f0f0f0fu : s == 1 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if (k & j) continue;
+            const unsigned t = ((a[k] >> j) ^ a[k | j]) & m;
+            a[k | j] ^= t;
+            a[k] ^= t << j;
+        }
+    }
+}
+
+// Number of keys (over the whole wavefront) strictly below T, 1 <= T <= 32768. Two
+// 15-bit keys per register, counted with plain 32-bit integer instructions (full rate
+// on this chip, where packed 16-bit ones run at half rate): per half-word,
+// ((T - 1) | 0x8000) - key lies in [1, 0xffff] -- no borrow crosses into the other
+// half -- and has bit 15 set exactly when key < T.
 template <int NP>
 __device__ __forceinline__ int count_less16(const unsigned (&kp)[NP], unsigned T)
 {
-    const unsigned short t = (unsigned short)T;
-    const u16x2 tt = {t, t};
-    u16x2 acc0 = {0, 0}, acc1 = {0, 0};
+    const unsigned tc = ((T - 1) | 0x8000u) * 0x10001u;
+    unsigned acc0 = 0, acc1 = 0;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        const u16x2 d = __builtin_bit_cast(u16x2, kp[i]) - tt;
+        const unsigned f = ((tc - kp[i]) >> 15) & 0x10001u;
         if (i & 1)
-            acc1 += d >> (unsigned short)15;
+            acc1 += f;
         else
-            acc0 += d >> (unsigned short)15;
+            acc0 += f;
     }
-    const u16x2 acc = acc0 + acc1;
-    return wave_sum_small<8>((int)acc.x + (int)acc.y);
+    const unsigned acc = acc0 + acc1;  // each half <= NP <= 32
+    return wave_sum_small<7>((int)((acc & 0xffffu) + (acc >> 16)));
 }
 
 // Append the exact |deviation| of every sample whose bit is set in `cand` (bit j <->
@@ -350,11 +383,56 @@ __device__ __forceinline__ void rank_in_list(const double *list, int n, int r, i
     }
 }
 
+// Common case of the MAD's last step: the median's key bin holds n <= 64 samples.
+// `v` / `c` are one candidate per lane (|float32 deviation| and channel; lanes >= n
+// idle). Order statistics are located on the float32 values -- rounding is monotone,
+// so exact order refines float32 order -- and only the candidates whose float32 value
+// equals that of rank r (or r - 1) are recomputed in float64, all in ONE pass, one
+// candidate per lane. Returns the exact values of rank r (xk) and, when want_prev and
+// r >= 1, of rank r - 1 (prev).
+template <int WIDTH, class Fetch>
+__device__ __forceinline__ void rank_bin64(float v, int c, int n, int r, bool want_prev, int lane,
+                                           Fetch &&fetch, double &xk, double &prev)
+{
+    const bool live = lane < n;
+    int lt = 0, eq_before = 0;
+    for (int jj = 0; jj < n; jj++) {
+        const float y = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), jj));
+        lt += (y < v);
+        eq_before += (y == v) && (jj < lane);
+    }
+    const int stable = lt + eq_before;
+    const int lane_r = __ffsll((long long)ksp_ballot(live && stable == r)) - 1;
+    const int lane_low =
+        (want_prev && r >= 1) ? __ffsll((long long)ksp_ballot(live && stable == r - 1)) - 1 : lane_r;
+    const float v_r = __shfl(v, lane_r, 64), v_low = __shfl(v, lane_low, 64);
+    const int below = __shfl(lt, lane_low, 64);  // candidates strictly below the tied set
+    const bool tied = live && (v == v_r || v == v_low);
+    const int c_any = __shfl(c, lane_r, 64);
+    const double x = fabs(exact_dev<WIDTH>(tied ? c : c_any, fetch));
+    // exact rank inside the tied set (usually one or two lanes)
+    int rs = below;
+    unsigned long long m = ksp_ballot(tied);
+    const int xlo = __double2loint(x), xhi = __double2hiint(x);
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const double y = __hiloint2double(__builtin_amdgcn_readlane(xhi, l),
+                                          __builtin_amdgcn_readlane(xlo, l));
+        rs += (y < x) || (y == x && l < lane);
+    }
+    xk = __shfl(x, __ffsll((long long)ksp_ballot(tied && rs == r)) - 1, 64);
+    prev = 0.0;
+    if (want_prev && r >= 1)
+        prev = __shfl(x, __ffsll((long long)ksp_ballot(tied && rs == r - 1)) - 1, 64);
+}
+
 // `list` is this wavefront's private candidate list in LDS (LIST_CAP doubles).
 // Returns the float64 noise estimate (NaN when every deviation is zero).
 template <int R, int WIDTH, int LIST_CAP, class Fetch>
 __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, double *list,
-                                            Fetch &&fetch)
+                                            Fetch &&fetch, int debug_stop = 0)
 {
     constexpr int NP = R / 2;
     const int c0 = lane * R;
@@ -362,14 +440,15 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     //    float32(|d|) is monotone in |d| and so is its truncation, hence the key bin of
     //    the median can be found without knowing any exact value.
     unsigned kp[NP];
-    int zeros = 0;
+    int zeros = 0;  // wave-uniform: a compare mask per sample, counted on the scalar unit
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        zeros += (dev[2 * i] == 0.0f) + (dev[2 * i + 1] == 0.0f);
-        kp[i] = ((__float_as_uint(dev[2 * i]) >> 16) & 0x7fffu) |
-                (__float_as_uint(dev[2 * i + 1]) & 0x7fff0000u);
+        zeros += __popcll(ksp_ballot(dev[2 * i] == 0.0f)) + __popcll(ksp_ballot(dev[2 * i + 1] == 0.0f));
+        // bytes 2,3 of each value side by side, sign bits cleared
+        kp[i] = __builtin_amdgcn_perm(__float_as_uint(dev[2 * i + 1]), __float_as_uint(dev[2 * i]),
+                                      0x07060302u) & 0x7fff7fffu;
     }
-    zeros = wave_sum_small<8>(zeros);
+    if (debug_stop == 31) return (double)(zeros + kp[0] + kp[NP - 1]);
     const int total = 64 * R;
     if (zeros == total) return __builtin_nan("");  // numpy: median of nothing
     const int rank2 = total + zeros;  // zeros sort first (reference rank.mako:261-266)
@@ -377,18 +456,43 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     const bool even = !(rank2 & 1);
     // 2. which key bin holds the median, and how many samples lie below the bin
     unsigned K = 0;
-    int below_bin = 0;
-    for (int bit = 14; bit >= 0; bit--) {
-        const unsigned test = K | (1u << bit);
-        const int c = count_less16<NP>(kp, test);
-        if (c <= rank) {
-            K = test;
-            below_bin = c;
+    int below_bin = 0, in_bin;
+    unsigned eq0 = 0, eq1 = 0;  // R == 64: which even / odd samples of the lane have key K
+    if constexpr (R == 64) {
+        // Bit-sliced search. The lane's 64 keys are transposed into 15 bit planes of
+        // 64 bits (np[b]: even samples, np[16 + b]: odd samples; stored inverted), so
+        // "how many of the keys that still match the prefix have bit b clear" is two
+        // ANDs and two population counts per lane instead of a pass over 32 registers.
+        unsigned np[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) np[i] = kp[i] ^ 0x7fff7fffu;
+        transpose_bits32(np);
+        eq0 = eq1 = 0xffffffffu;
+#pragma unroll
+        for (int bit = 14; bit >= 0; bit--) {
+            const unsigned z0 = eq0 & np[bit], z1 = eq1 & np[16 + bit];  // bit clear: below
+            const int c = below_bin + ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
+            const bool take = c <= rank;  // wave-uniform: the median's key has this bit set
+            K |= take ? (1u << bit) : 0u;
+            below_bin = take ? c : below_bin;
+            eq0 = take ? (eq0 ^ z0) : z0;
+            eq1 = take ? (eq1 ^ z1) : z1;
         }
+        in_bin = ksp_wave_sum_dpp(__popc(eq0) + __popc(eq1));
+    } else {
+        for (int bit = 14; bit >= 0; bit--) {
+            const unsigned test = K | (1u << bit);
+            const int c = count_less16<NP>(kp, test);
+            if (c <= rank) {
+                K = test;
+                below_bin = c;
+            }
+        }
+        in_bin = count_less16<NP>(kp, K + 1) - below_bin;
     }
-    auto key_of = [&](int j) -> unsigned {
-        return (j & 1) ? (kp[j / 2] >> 16) : (kp[j / 2] & 0xffffu);
-    };
+    if (debug_stop == 32) return (double)(K + below_bin);
+    // (keys are re-derived from the deviations from here on: kp may die)
+    auto key_of = [&](int j) -> unsigned { return (__float_as_uint(dev[j]) >> 16) & 0x7fffu; };
     auto bin_mask = [&](unsigned key) -> unsigned long long {
         unsigned long long m = 0;
 #pragma unroll
@@ -396,10 +500,10 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             if (key_of(j) == key) m |= 1ull << j;
         return m;
     };
-    int in_bin = count_less16<NP>(kp, K + 1) - below_bin;
     int r = rank - below_bin;  // 0-based rank inside the bin
-    unsigned long long cand = bin_mask(K);
-    if (in_bin > LIST_CAP) {
+    unsigned long long cand = 0;
+    const bool narrowed = in_bin > LIST_CAP;
+    if (narrowed) {
         // Degenerate data (hundreds of samples in one key bin, e.g. quantised input):
         // narrow the bin with an exact search on the full float32 patterns, which
         // leaves only samples whose float32 deviations are identical.
@@ -463,12 +567,48 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             return xk * FUSED_MAD_NORMAL;
         }
     }
-    // 3. recompute the bin's (few) samples exactly and rank them in float64
-    gather_exact<WIDTH>(cand, c0, list, 0, LIST_CAP, fetch);
     double xk, prev;
     bool have_prev;
-    rank_in_list(list, in_bin, r, lane, xk, prev, have_prev);
-    __builtin_amdgcn_wave_barrier();
+    if (!narrowed && in_bin <= 64) {
+        // 3a. usual case: hand the bin's samples out one per lane (float32 value and
+        //     channel go through the list), rank on float32, recompute only the ties
+        float *lv = (float *)list;
+        int *lc = (int *)list + 64;
+        int n = 0;
+        unsigned any0 = 0xffffffffu, any1 = 0xffffffffu;  // sample slots with a hit in some lane
+        if constexpr (R == 64) {
+            any0 = ksp_wave_or_dpp(eq0);
+            any1 = ksp_wave_or_dpp(eq1);
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (!((((j & 1) ? any1 : any0) >> (j / 2)) & 1)) continue;  // scalar test
+            const bool hit = (R == 64) ? ((((j & 1) ? eq1 : eq0) >> (j / 2)) & 1) : (key_of(j) == K);
+            const unsigned long long m = ksp_ballot(hit);
+            if (m) {
+                const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if (hit) {
+                    lv[pos] = fabsf(dev[j]);
+                    lc[pos] = c0 + j;
+                }
+                n += __popcll(m);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float v = lane < n ? lv[lane] : 0.0f;
+        const int c = lane < n ? lc[lane] : 0;
+        if (debug_stop == 33) return (double)(v + c);
+        rank_bin64<WIDTH>(v, c, n, r, even, lane, fetch, xk, prev);
+        have_prev = r >= 1;
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        // 3b. recompute all of the bin's samples exactly and rank them in float64
+        gather_exact<WIDTH>(narrowed ? cand : bin_mask(K), c0, list, 0, LIST_CAP, fetch);
+        rank_in_list(list, in_bin, r, lane, xk, prev, have_prev);
+        __builtin_amdgcn_wave_barrier();
+    }
     if (even && !have_prev) {
         // r == 0: the lower median is the largest value below the bin, i.e. the
         // largest exact value of the highest non-empty bin below K

@@ -60,6 +60,32 @@ __device__ __forceinline__ unsigned long long ksp_ballot(bool x)
 }
 __device__ __forceinline__ bool ksp_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
 
+// Wavefront reductions on the DPP network (no LDS round trip, result wave-uniform):
+// four row shifts leave each row's total in its lane 15, row_bcast:15 / row_bcast:31
+// carry the totals across rows into lane 63.
+#define KSP_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, 0xf, true)
+__device__ __forceinline__ int ksp_wave_sum_dpp(int v)
+{
+    v += KSP_DPP(v, 0x111, 0xf);  // row_shr:1
+    v += KSP_DPP(v, 0x112, 0xf);  // row_shr:2
+    v += KSP_DPP(v, 0x114, 0xf);  // row_shr:4
+    v += KSP_DPP(v, 0x118, 0xf);  // row_shr:8
+    v += KSP_DPP(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    v += KSP_DPP(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned ksp_wave_or_dpp(unsigned u)
+{
+    int v = (int)u;
+    v |= KSP_DPP(v, 0x111, 0xf);
+    v |= KSP_DPP(v, 0x112, 0xf);
+    v |= KSP_DPP(v, 0x114, 0xf);
+    v |= KSP_DPP(v, 0x118, 0xf);
+    v |= KSP_DPP(v, 0x142, 0xa);
+    v |= KSP_DPP(v, 0x143, 0xc);
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int ksp_wave_sum(int v)
 {
 #pragma unroll

@@ -25,8 +25,8 @@ rs = np.random.RandomState(1)
 vis = (rs.standard_normal((channels, baselines)).astype(np.float32)
        + 1j * rs.standard_normal((channels, baselines)).astype(np.float32)).astype(np.complex64)
 fn.buffer("vis").set(q, vis)
-names = {11: "load-noamp", 1: "load", 2: "+median", 31: "+zeros", 32: "+bisect", 33: "+gather", 34: "+rank", 35: "+below", 36: "+noise64", 3: "+mad", 4: "+threshold", 0: "full"}
-for stop in (11, 1, 2, 3, 4, 0):
+names = {11: "load-noamp", 1: "load", 2: "+median", 31: "+keys", 32: "+bitsearch", 33: "+gather", 34: "+rank", 35: "+below", 36: "+noise64", 3: "+mad", 4: "+threshold", 0: "full"}
+for stop in (1, 2, 31, 32, 33, 3, 4, 0):
     os.environ["KSP_FUSED_DEBUG_STOP"] = str(stop)
     fn(); q.finish()
     a = q.enqueue_marker()
