@@ -170,6 +170,17 @@ int ksp_flagger_fused(int device, void *stream, const void *vis, const uint8_t *
  * back to the kernel-per-stage sequence). */
 int ksp_flagger_fused_supported(int channels, int width, int n_windows);
 
+/* Self-tests of the arithmetic building blocks (no reference counterpart; they exist
+ * so that the test-suite can pin device arithmetic against IEEE / numpy results).
+ * ksp_selftest_sqrt12: out[i] = the kernels' square root of the float32 with bit
+ *   pattern 0x3f800000 + i (i.e. every float32 from 1.0 upwards; n <= 2^23 + 1 covers
+ *   [1, 2]), to be compared with a correctly rounded sqrt.
+ * ksp_selftest_abs: out[i] = the kernels' |re[i] + j im[i]| (numpy's complex64 abs,
+ *   rfi/host.py:137). All pointers are device pointers. */
+int ksp_selftest_sqrt12(int device, void *stream, float *out, int n);
+int ksp_selftest_abs(int device, void *stream, const float *re, const float *im, float *out,
+                     int n);
+
 #ifdef __cplusplus
 }
 #endif

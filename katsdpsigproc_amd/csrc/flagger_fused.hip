@@ -40,8 +40,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     const int C = p.channels;
     const int b0 = strip_of(blockIdx.x, p.n_strips) * FUSED_STRIP;
 
+    // diagnostic time stamps (shader clock) of this wavefront's phases
+    unsigned long long *trace = p.trace ? p.trace + ((size_t)blockIdx.x * FUSED_STRIP + wave) * 8 : nullptr;
+    auto stamp = [&](int i) {
+        if (trace != nullptr && lane == 0) trace[i] = __builtin_amdgcn_s_memtime();
+    };
+    if (trace != nullptr && lane == 0)
+        trace[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    stamp(0);
     load_strip<R>(p, lds, b0, tid);
+    stamp(1);
     __syncthreads();
+    stamp(2);
     if (p.debug_stop == 1) return;
 
     const int bl = b0 + wave;
@@ -54,6 +64,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     float dev[R];
     float dmax;
     median_phase<R, WIDTH>(myrow, lane, dev, dmax);
+    stamp(3);
     // From here on the arguments are re-read from the kernarg segment (scalar loads):
     // keeping some 30 argument registers alive across the median phase would starve
     // it of the scalar registers its lane masks live in.
@@ -70,10 +81,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
 
     const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, pa.debug_stop);
     if (lane == 0 && pa.noise != nullptr && bl < pa.baselines) pa.noise[bl] = (float)noise64;
+    stamp(4);
     if (pa.debug_stop == 3 || pa.debug_stop > 30) return;
 
     const unsigned long long fl =
         threshold_flags<R, WIDTH>(pa, dev, dmax, noise64, lane, C, fetch);
+    stamp(5);
     if (pa.debug_stop == 4) {
         if (fl == 0x123456789abcull && pa.noise) pa.noise[0] = 1.0f;
         return;
@@ -102,6 +115,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         }
     }
     write_flags(pa, fl, lane * R, bl, C);
+    stamp(6);
 }
 
 // =================================================================================
@@ -119,9 +133,35 @@ static int launch_fused(hipStream_t s, const FusedParams &p)
         KSP_CHECK(hipFuncSetAttribute((const void *)kern,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
+        if (getenv("KSP_FUSED_DEBUG_OCC")) {
+            int nb = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FUSED_THREADS, lds_bytes);
+            fprintf(stderr, "flagger_fused_kernel<%d>: %d workgroups/CU, LDS %zu B\n", R, nb, lds_bytes);
+        }
     }
-    hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
+    const char *trace_path = getenv("KSP_FUSED_DEBUG_TRACE");
+    if (trace_path == nullptr) {
+        hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
+        KSP_LAUNCH_CHECK();
+        return 0;
+    }
+    // diagnostic run: collect per-wavefront phase time stamps and dump them
+    FusedParams pt = p;
+    const size_t n = (size_t)p.n_strips * FUSED_STRIP * 8;
+    KSP_CHECK(hipMalloc(&pt.trace, n * 8));
+    KSP_CHECK(hipMemsetAsync(pt.trace, 0, n * 8, s));
+    hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, pt);
     KSP_LAUNCH_CHECK();
+    KSP_CHECK(hipStreamSynchronize(s));
+    unsigned long long *host = (unsigned long long *)malloc(n * 8);
+    KSP_CHECK(hipMemcpy(host, pt.trace, n * 8, hipMemcpyDeviceToHost));
+    KSP_CHECK(hipFree(pt.trace));
+    FILE *f = fopen(trace_path, "wb");
+    if (f != nullptr) {
+        fwrite(host, 8, n, f);
+        fclose(f);
+    }
+    free(host);
     return 0;
 }
 
@@ -178,6 +218,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     p.n_windows = n_windows;
     p.flag_value = flag_value;
     p.n_strips = ksp_divup(baselines, FUSED_STRIP);
+    p.trace = nullptr;
     {
         const char *dbg = getenv("KSP_FUSED_DEBUG_STOP");
         p.debug_stop = dbg ? atoi(dbg) : 0;

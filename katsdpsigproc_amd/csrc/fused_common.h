@@ -23,6 +23,7 @@ struct FusedParams {
     int is_amplitude, flags_mode, threshold_kind, n_windows, flag_value;
     int n_strips;
     int debug_stop;  // diagnostic only (env KSP_FUSED_DEBUG_STOP): 0 = run everything
+    unsigned long long *trace;  // diagnostic only (env KSP_FUSED_DEBUG_TRACE): phase time stamps
     double n_sigma;
     double scales[KSP_MAX_WINDOWS];
 };
@@ -74,7 +75,7 @@ template <int R>
 __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int b0, int tid)
 {
     using LY = FusedLayout<R>;
-    constexpr int LB = 8;
+    constexpr int LB = 4;
     constexpr int LPR = FUSED_STRIP / 2;            // lanes per row segment
     constexpr int RSTEP = FUSED_THREADS / LPR;      // rows covered per pass
     const int C = p.channels;

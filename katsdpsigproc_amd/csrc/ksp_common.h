@@ -33,20 +33,37 @@ void ksp_set_error(const char *fmt, ...);
 static inline int ksp_divup(int a, int b) { return (a + b - 1) / b; }
 
 #ifdef __HIPCC__
+// Correctly rounded float32 square root for 1 <= x <= 2 (NaN passes through): one
+// Newton step on x * rsq(x) with the residual taken exactly by an fma. The general
+// expansion the compiler emits spends a dozen instructions on scaling and special
+// cases that cannot occur in this interval; this one is checked against IEEE sqrt
+// for EVERY float32 in [1, 2] (tests/test_gpu_ops.py, ksp_selftest_sqrt12).
+__device__ __forceinline__ float ksp_sqrt_1_2(float x)
+{
+    const float q = __builtin_amdgcn_rsqf(x);
+    const float g = __fmul_rn(x, q);
+    const float h = __fmul_rn(0.5f, q);
+    const float r = __fmaf_rn(-g, g, x);
+    return __fmaf_rn(h, r, g);
+}
+
 // numpy's complex64 abs: mx * sqrt(fma(r, r, 1)), r = mn / mx, with IEEE
 // division and square root (pinned by tests/golden abs probe; the reference
 // host path computes np.abs(vis), rfi/host.py:137).
+// |x| bit patterns order like unsigned integers with the NaNs on top, so max/min on
+// the patterns give mx/mn with a NaN operand propagating by itself.
 __device__ __forceinline__ float ksp_abs_c64(float re, float im)
 {
-    float ar = fabsf(re), ai = fabsf(im);
-    float mx = fmaxf(ar, ai);  // fmaxf ignores a NaN operand; handled below
-    float mn = fminf(ar, ai);
-    float r = __fdiv_rn(mn, mx);
-    float t = __fmaf_rn(r, r, 1.0f);
-    float a = __fmul_rn(mx, __builtin_sqrtf(t));
-    if (mx == 0.0f) a = 0.0f;
-    if (ar != ar || ai != ai) a = __builtin_nanf("");
-    if (mx == __builtin_inff()) a = mx;
+    const unsigned ur = __float_as_uint(re) & 0x7fffffffu;
+    const unsigned ui = __float_as_uint(im) & 0x7fffffffu;
+    const unsigned umx = max(ur, ui), umn = min(ur, ui);
+    const float mx = __uint_as_float(umx), mn = __uint_as_float(umn);
+    // divide by at least the smallest denormal: 0 / 0 becomes 0 / tiny = 0 (-> |0| = 0)
+    const float r = __fdiv_rn(mn, __uint_as_float(max(umx, 1u)));
+    const float t = __fmaf_rn(r, r, 1.0f);  // in [1, 2]
+    float a = __fmul_rn(mx, ksp_sqrt_1_2(t));
+    // (inf, inf) and (inf, NaN) arrive here as NaN; hypot says inf
+    if (umn == 0x7f800000u) a = __builtin_inff();
     return a;
 }
 

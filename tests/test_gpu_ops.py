@@ -341,3 +341,67 @@ class TestThreshold:
         ):
             out = self._run(template, command_queue, dev, noise, n_sigma=11.0)
             np.testing.assert_array_equal(out.astype(np.bool_), spikes)
+
+
+class TestArithmetic:
+    """The kernels' arithmetic building blocks against IEEE / numpy (C-ABI self-tests)."""
+
+    @staticmethod
+    def _run(name, n_out, *host_inputs):
+        import ctypes
+
+        from katsdpsigproc_amd import _lib
+
+        lib = _lib.load()
+        bufs = []
+        try:
+            for arr in host_inputs:
+                d = ctypes.c_void_p()
+                assert lib.ksp_malloc(0, arr.nbytes, ctypes.byref(d)) == 0
+                bufs.append(d)
+                assert lib.ksp_memcpy_async(0, d, arr.ctypes.data_as(ctypes.c_void_p),
+                                            arr.nbytes, 0, None) == 0  # fmt: skip
+            d_out = ctypes.c_void_p()
+            assert lib.ksp_malloc(0, 4 * n_out, ctypes.byref(d_out)) == 0
+            bufs.append(d_out)
+            rc = getattr(lib, name)(0, None, *bufs, n_out)
+            assert rc == 0, _lib.last_error()
+            out = np.empty(n_out, np.float32)
+            assert lib.ksp_memcpy_async(0, out.ctypes.data_as(ctypes.c_void_p), d_out,
+                                        out.nbytes, 1, None) == 0  # fmt: skip
+            assert lib.ksp_stream_synchronize(0, None) == 0
+            return out
+        finally:
+            for d in bufs:
+                lib.ksp_free(0, d)
+
+    def test_sqrt_exhaustive(self):
+        """Every float32 in [1, 2]: the restricted-range sqrt is correctly rounded."""
+        n = (1 << 23) + 1
+        out = self._run("ksp_selftest_sqrt12", n)
+        x = (np.arange(n, dtype=np.uint32) + np.uint32(0x3F800000)).view(np.float32)
+        assert x[0] == 1.0 and x[-1] == 2.0
+        expected = np.sqrt(x.astype(np.float64)).astype(np.float32)  # exact: no double rounding
+        np.testing.assert_array_equal(np.sqrt(x), expected)  # numpy's float32 sqrt is IEEE too
+        np.testing.assert_array_equal(out, expected)
+
+    def test_abs_matches_numpy(self, oracle):
+        """|z| is numpy's complex64 abs bit for bit: random magnitudes over the whole
+        exponent range, equal parts, zeros, denormals, infinities and NaNs."""
+        rs = np.random.RandomState(77)
+        n = 1 << 20
+        scale = np.exp2(rs.uniform(-140, 127, n)).astype(np.float32)
+        re = (rs.standard_normal(n) * scale).astype(np.float32)
+        im = (rs.standard_normal(n) * scale * np.exp2(rs.uniform(-30, 30, n))).astype(np.float32)
+        special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38,
+                            3.4e38, 1.17549435e-38, 2.0, 0.5], np.float32)  # fmt: skip
+        sr, si = np.meshgrid(special, special)
+        re = np.concatenate([re, sr.ravel(), re[:1000]])
+        im = np.concatenate([im, si.ravel(), re[:1000]])
+        out = self._run("ksp_selftest_abs", len(re), re, im)
+        with np.errstate(all="ignore"):
+            z = np.empty(len(re), np.complex64)
+            z.real, z.imag = re, im
+            expected = np.abs(z)
+        np.testing.assert_array_equal(out, expected)  # NaN == NaN here
+        np.testing.assert_array_equal(out, oracle.abs_c64(z))

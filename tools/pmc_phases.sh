@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_phases.txt
 : > $OUT
-for stop in 1 2 3 0; do
+for stop in ${STOPS:-1 2 3 0}; do
   export KSP_FUSED_DEBUG_STOP=$stop N=2
   rm -rf /tmp/pmc_$stop
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d /tmp/pmc_$stop -o p --output-format csv -- python3 $R/tools/run_fused.py > /tmp/pmc_$stop.log 2>&1 || { tail -5 /tmp/pmc_$stop.log; exit 1; }
