@@ -48,7 +48,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     if (trace != nullptr && lane == 0)
         trace[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
     stamp(0);
-    load_strip<R>(p, lds, b0, tid);
+    if (!p.is_amplitude && b0 + FUSED_STRIP <= p.baselines) {
+        if (p.flags_mode == KSP_FLAGS_NONE)
+            load_strip_fast<R, KSP_FLAGS_NONE>(p, lds, b0, tid);
+        else if (p.flags_mode == KSP_FLAGS_CHANNEL)
+            load_strip_fast<R, KSP_FLAGS_CHANNEL>(p, lds, b0, tid);
+        else
+            load_strip_fast<R, KSP_FLAGS_FULL>(p, lds, b0, tid);
+    } else {
+        load_strip<R>(p, lds, b0, tid);
+    }
     stamp(1);
     __syncthreads();
     stamp(2);

@@ -84,24 +84,38 @@ __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int
     const int bl = b0 + 2 * q;
     const bool ok0 = bl < p.baselines, ok1 = bl + 1 < p.baselines;
     const bool plain = !p.is_amplitude && ok1;
-    auto request = [&](float4 (&raw)[LB], int rbase) {
+    // flags of the two samples a lane owns in a row: bit 0 / bit 8 (requested together
+    // with the visibilities so that they do not serialise the loop)
+    auto request = [&](float4 (&raw)[LB], unsigned (&fl)[LB], int rbase) {
 #pragma unroll
         for (int u = 0; u < LB; u++) {
             const int row = rbase + u * RSTEP;
             raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (plain && row < C)
+            fl[u] = 0;
+            if (plain && row < C) {
                 raw[u] = *(const float4 *)((const float2 *)p.vis + (size_t)row * p.vis_stride + bl);
+                // (only loads here: any arithmetic on the bytes would wait for them)
+                if (p.flags_mode == KSP_FLAGS_CHANNEL) {
+                    fl[u] = p.in_flags[row];
+                } else if (p.flags_mode == KSP_FLAGS_FULL) {
+                    fl[u] = *(const unsigned short *)(p.in_flags + (size_t)row * p.in_flags_stride + bl);
+                }
+            }
         }
     };
-    auto finish = [&](const float4 (&raw)[LB], int rbase) {
+    auto finish = [&](const float4 (&raw)[LB], const unsigned (&fl)[LB], int rbase) {
 #pragma unroll
         for (int u = 0; u < LB; u++) {
             const int row = rbase + u * RSTEP;
             if (row >= C) break;
             float a0 = __builtin_nanf(""), a1 = __builtin_nanf("");
+            unsigned fl8;
             if (plain) {
-                a0 = amp_with_flags(p, raw[u].x, raw[u].y, row, bl);
-                a1 = amp_with_flags(p, raw[u].z, raw[u].w, row, bl + 1);
+                a0 = ksp_abs_c64(raw[u].x, raw[u].y);
+                a1 = ksp_abs_c64(raw[u].z, raw[u].w);
+                if (p.flags_mode == KSP_FLAGS_CHANNEL) fl8 = fl[u] ? 0x101u : 0u; else fl8 = fl[u];
+                if (fl8 & 0xffu) a0 = __builtin_nanf("");
+                if (fl8 >> 8) a1 = __builtin_nanf("");
             } else if (p.is_amplitude) {
                 const float *src = (const float *)p.vis + (size_t)row * p.vis_stride + bl;
                 if (ok0) a0 = src[0];
@@ -114,6 +128,7 @@ __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int
                     if (ok1 && f[1]) a1 = __builtin_nanf("");
                 }
             } else if (ok0) {
+                // last, odd baseline of a ragged strip
                 const float2 v = ((const float2 *)p.vis)[(size_t)row * p.vis_stride + bl];
                 a0 = amp_with_flags(p, v.x, v.y, row, bl);
             }
@@ -124,13 +139,84 @@ __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int
     };
     constexpr int BATCH = RSTEP * LB;
     float4 bufa[LB], bufb[LB];
-    request(bufa, r0);
+    unsigned fla[LB], flb[LB];
+    request(bufa, fla, r0);
     for (int rbase = r0; rbase < C; rbase += 2 * BATCH) {
-        if (rbase + BATCH < C) request(bufb, rbase + BATCH);
-        finish(bufa, rbase);
+        if (rbase + BATCH < C) request(bufb, flb, rbase + BATCH);
+        finish(bufa, fla, rbase);
         if (rbase + BATCH < C) {
-            if (rbase + 2 * BATCH < C) request(bufa, rbase + 2 * BATCH);
-            finish(bufb, rbase + BATCH);
+            if (rbase + 2 * BATCH < C) request(bufa, fla, rbase + 2 * BATCH);
+            finish(bufb, flb, rbase + BATCH);
+        }
+    }
+    // channels C .. 64 R - 1 do not exist; the median phase expects NaN there
+    for (int row = C + r0; row < 64 * R; row += RSTEP) {
+        const int idx = LY::index(row);
+        lds[(2 * q) * LY::ROW + idx] = __builtin_nanf("");
+        lds[(2 * q + 1) * LY::ROW + idx] = __builtin_nanf("");
+    }
+}
+
+// Fast form of load_strip for complex input and a strip that lies wholly inside the
+// array (all but possibly the last one): every lane issues the same straight-line
+// sequence of loads -- rows past the end are clamped, their results dropped -- so the
+// hardware counters, not conservative waits at branch joins, pace the double buffer.
+// MODE is the input-flags mode, fixed per launch.
+template <int R, int MODE>
+__device__ __forceinline__ void load_strip_fast(const FusedParams &p, float *lds, int b0, int tid)
+{
+    using LY = FusedLayout<R>;
+    constexpr int LB = 4;
+    constexpr int LPR = FUSED_STRIP / 2;
+    constexpr int RSTEP = FUSED_THREADS / LPR;
+    constexpr int BATCH = RSTEP * LB;
+    const int C = p.channels;
+    const int q = tid % LPR;
+    const int r0 = tid / LPR;
+    const int bl = b0 + 2 * q;
+    const float2 *vis = (const float2 *)p.vis + bl;
+    const size_t stride = (size_t)p.vis_stride;
+    auto request = [&](float4 (&raw)[LB], unsigned (&fl)[LB], int rbase) {
+#pragma unroll
+        for (int u = 0; u < LB; u++) {
+            const int row = min(rbase + r0 + u * RSTEP, C - 1);
+            raw[u] = *(const float4 *)(vis + (size_t)row * stride);
+            fl[u] = 0;
+            // (only loads here: any arithmetic on the bytes would wait for them)
+            if (MODE == KSP_FLAGS_CHANNEL)
+                fl[u] = p.in_flags[row];
+            else if (MODE == KSP_FLAGS_FULL)
+                fl[u] = *(const unsigned short *)(p.in_flags + (size_t)row * p.in_flags_stride + bl);
+        }
+    };
+    auto finish = [&](const float4 (&raw)[LB], const unsigned (&fl)[LB], int rbase) {
+#pragma unroll
+        for (int u = 0; u < LB; u++) {
+            const int row = rbase + r0 + u * RSTEP;
+            float a0 = ksp_abs_c64(raw[u].x, raw[u].y);
+            float a1 = ksp_abs_c64(raw[u].z, raw[u].w);
+            if (MODE == KSP_FLAGS_CHANNEL) {
+                if (fl[u]) a0 = a1 = __builtin_nanf("");
+            } else if (MODE == KSP_FLAGS_FULL) {
+                if (fl[u] & 0xffu) a0 = __builtin_nanf("");
+                if (fl[u] >> 8) a1 = __builtin_nanf("");
+            }
+            if (row < C) {
+                const int idx = LY::index(row);
+                lds[(2 * q) * LY::ROW + idx] = a0;
+                lds[(2 * q + 1) * LY::ROW + idx] = a1;
+            }
+        }
+    };
+    float4 bufa[LB], bufb[LB];
+    unsigned fla[LB], flb[LB];
+    request(bufa, fla, 0);
+    for (int rb = 0; rb < C; rb += 2 * BATCH) {  // wave-uniform bounds
+        if (rb + BATCH < C) request(bufb, flb, rb + BATCH);
+        finish(bufa, fla, rb);
+        if (rb + BATCH < C) {
+            if (rb + 2 * BATCH < C) request(bufa, fla, rb + 2 * BATCH);
+            finish(bufb, flb, rb + BATCH);
         }
     }
     // channels C .. 64 R - 1 do not exist; the median phase expects NaN there

@@ -15,8 +15,9 @@ channels = int(os.environ.get("CH", 4096))
 baselines = int(os.environ.get("BL", 32768))
 ctx = accel.create_some_context(False)
 q = ctx.create_command_queue()
+use_flags = getattr(device.BackgroundFlags, os.environ.get("FLAGS", "NONE"))
 t = device.FlaggerDeviceTemplate(
-    device.BackgroundMedianFilterDeviceTemplate(ctx, 13),
+    device.BackgroundMedianFilterDeviceTemplate(ctx, 13, use_flags=use_flags),
     device.NoiseEstMADTDeviceTemplate(ctx, 10240),
     device.ThresholdSumDeviceTemplate(ctx), keep_deviations=False)
 fn = t.instantiate(q, channels, baselines, threshold_args={"n_sigma": 11.0})
@@ -25,6 +26,10 @@ rs = np.random.RandomState(1)
 vis = (rs.standard_normal((channels, baselines)).astype(np.float32)
        + 1j * rs.standard_normal((channels, baselines)).astype(np.float32)).astype(np.complex64)
 fn.buffer("vis").set(q, vis)
+if use_flags == device.BackgroundFlags.CHANNEL:
+    fn.buffer("input_flags").set(q, (rs.random_sample(channels) < 1 / 16).astype(np.uint8))
+elif use_flags == device.BackgroundFlags.FULL:
+    fn.buffer("input_flags").set(q, (rs.random_sample((channels, baselines)) < 1 / 16).astype(np.uint8))
 names = {11: "load-noamp", 1: "load", 2: "+median", 31: "+keys", 32: "+bitsearch", 33: "+gather", 34: "+rank", 35: "+below", 36: "+noise64", 3: "+mad", 4: "+threshold", 0: "full"}
 for stop in (1, 2, 31, 32, 33, 3, 4, 0):
     os.environ["KSP_FUSED_DEBUG_STOP"] = str(stop)
