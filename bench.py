@@ -95,6 +95,23 @@ def cpu_baseline(budget_s: float = 20.0):
     }
 
 
+def measured_traffic(channels, baselines, use_flags, args):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json, collected by tools/pmc_mem.sh as the micro-architecture
+    guide prescribes); None when no pass exists for this exact workload."""
+    if args.sequence or args.keep_deviations:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            for entry in json.load(f):
+                if (entry["channels"], entry["baselines"], entry["use_flags"]) == \
+                        (channels, baselines, use_flags):
+                    return entry["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -186,8 +203,12 @@ def main() -> None:
         dist.barrier()
     sync()
     start_evt = queue.enqueue_marker()
+    kernel_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if not args.sequence:
+            # HIP events recorded around the flagger kernel itself, on its stream
+            kernel_events.append(fn.profile_next_run())
         step()
     end_evt = queue.enqueue_marker()
     sync()
@@ -195,6 +216,8 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     device_s = end_evt.time_since(start_evt)
+    if kernel_events:
+        device_s = sum(stop.time_since(start) for start, stop in kernel_events)
     if dist is not None:
         t = torch.tensor([elapsed, device_s], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,8 +225,9 @@ def main() -> None:
 
     samples_per_step = channels * baselines * world
     value = samples_per_step * args.steps / elapsed
-    # dominant kernel: with the fused path the step IS one kernel; its average launch
-    # duration is the HIP-event time on the launch stream divided by the steps
+    # dominant kernel: flagger_fused_kernel; its average launch duration comes from the
+    # HIP events armed around every launch (the zero-fill of the flags, a separate
+    # memset kernel of ~19 us, is part of the step but not of this kernel)
     kernel_s = device_s / args.steps
     n_bytes = ALGORITHMIC_BYTES_PER_SAMPLE + (4 if args.keep_deviations else 0)
     achieved = channels * baselines * n_bytes / kernel_s / 1e9
@@ -241,7 +265,7 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_sample": n_bytes,
                 "kernel_ms": 1e3 * kernel_s,
-                "traffic": None,
+                "traffic": measured_traffic(channels, baselines, use_flags.name, args),
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -166,6 +166,13 @@ int ksp_flagger_fused(int device, void *stream, const void *vis, const uint8_t *
                       int threshold_kind, double n_sigma, const double *scales64, int n_windows,
                       int flag_value);
 
+/* Arms two events (from ksp_event_create) for the calling thread's NEXT
+ * ksp_flagger_fused call: they are recorded immediately before and after the flagger
+ * kernel itself, excluding the zero-fill of flags that precedes it (the counterpart of
+ * the reference's per-kernel profiling, abc.py:405-432 / TuningCommandQueue). Pass
+ * NULL, NULL to disarm. */
+int ksp_flagger_fused_profile(void *start_event, void *stop_event);
+
 /* Returns 1 if ksp_flagger_fused supports this configuration (else callers fall
  * back to the kernel-per-stage sequence). */
 int ksp_flagger_fused_supported(int channels, int width, int n_windows);

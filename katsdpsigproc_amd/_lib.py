@@ -68,6 +68,7 @@ SIGNATURES = {
     "ksp_maskedsum_float": [
         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int
     ],
+    "ksp_flagger_fused_profile": [c_void_p, c_void_p],
     "ksp_selftest_sqrt12": [c_int, c_void_p, c_void_p, c_int],
     "ksp_selftest_abs": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "ksp_background_median_filter": [

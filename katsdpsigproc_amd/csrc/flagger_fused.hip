@@ -27,6 +27,10 @@
 //
 // Roofline: HBM, 9 algorithmic bytes per sample (8 read + 1 written).
 #include "fused_common.h"
+#include <hip/hip_ext.h>
+
+// Events armed by ksp_flagger_fused_profile for the NEXT fused launch of this thread.
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 
 // =================================================================================
 template <int R, int WIDTH>
@@ -150,7 +154,14 @@ static int launch_fused(hipStream_t s, const FusedParams &p)
     }
     const char *trace_path = getenv("KSP_FUSED_DEBUG_TRACE");
     if (trace_path == nullptr) {
-        hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
+        if (g_prof_start != nullptr) {
+            // time exactly this kernel (not the zero-fill before it)
+            hipExtLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s,
+                                  g_prof_start, g_prof_stop, 0, p);
+            g_prof_start = g_prof_stop = nullptr;
+        } else {
+            hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
+        }
         KSP_LAUNCH_CHECK();
         return 0;
     }
@@ -171,6 +182,14 @@ static int launch_fused(hipStream_t s, const FusedParams &p)
         fclose(f);
     }
     free(host);
+    return 0;
+}
+
+extern "C" int ksp_flagger_fused_profile(void *start_event, void *stop_event)
+{
+    KSP_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "need both events or none");
+    g_prof_start = (hipEvent_t)start_event;
+    g_prof_stop = (hipEvent_t)stop_event;
     return 0;
 }
 

@@ -389,6 +389,12 @@ class CommandQueue(AbstractCommandQueue):
         _lib.call("ksp_event_record", self._dev, ctypes.c_void_p(event.handle), self._s)
         return event
 
+    def create_event(self) -> Event:
+        """An event that has not been recorded yet (for kernel-level profiling hooks)."""
+        handle = ctypes.c_void_p()
+        _lib.call("ksp_event_create", self._dev, ctypes.byref(handle))
+        return Event(self._dev, handle.value)
+
     def enqueue_wait_for_events(self, events: Sequence[Event]) -> None:
         for event in events:
             _lib.call("ksp_stream_wait_event", self._dev, self._s, ctypes.c_void_p(event.handle))

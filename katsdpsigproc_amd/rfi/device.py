@@ -13,6 +13,7 @@ As in the reference, noise estimators and thresholders may work on transposed
 inserts transposes where needed.
 """
 
+import ctypes
 import enum
 from abc import ABC, abstractmethod
 from typing import Any, List, Mapping, Optional, Tuple, Type, Union
@@ -887,6 +888,18 @@ class FusedFlaggerDevice(accel.Operation):
                 np.int32(self.template.threshold.flag_value),
             ],
         )
+
+    def profile_next_run(self):
+        """Arm two events around the flagger kernel of the next call (excluding the
+        zero-fill of `flags` that precedes it); returns (start, stop). After the queue
+        has finished, ``stop.time_since(start)`` is that kernel's duration."""
+        from .. import _lib
+
+        queue = self.command_queue
+        start, stop = queue.create_event(), queue.create_event()
+        _lib.call("ksp_flagger_fused_profile", ctypes.c_void_p(start.handle),
+                  ctypes.c_void_p(stop.handle))  # fmt: skip
+        return start, stop
 
     def parameters(self) -> Mapping[str, Any]:
         return {
