@@ -52,18 +52,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     if (trace != nullptr && lane == 0)
         trace[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
     stamp(0);
+    bool masked = true;  // may the strip hold samples that take no part (NaN in LDS)?
     if (!p.is_amplitude && b0 + FUSED_STRIP <= p.baselines) {
         if (p.flags_mode == KSP_FLAGS_NONE)
-            load_strip_fast<R, KSP_FLAGS_NONE>(p, lds, b0, tid);
+            masked = load_strip_fast<R, KSP_FLAGS_NONE>(p, lds, b0, tid);
         else if (p.flags_mode == KSP_FLAGS_CHANNEL)
-            load_strip_fast<R, KSP_FLAGS_CHANNEL>(p, lds, b0, tid);
+            masked = load_strip_fast<R, KSP_FLAGS_CHANNEL>(p, lds, b0, tid);
         else
-            load_strip_fast<R, KSP_FLAGS_FULL>(p, lds, b0, tid);
+            masked = load_strip_fast<R, KSP_FLAGS_FULL>(p, lds, b0, tid);
     } else {
         load_strip<R>(p, lds, b0, tid);
     }
     stamp(1);
-    __syncthreads();
+    const bool any_masked = __syncthreads_or(masked);
     stamp(2);
     if (p.debug_stop == 1) return;
 
@@ -76,7 +77,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     };
     float dev[R];
     float dmax;
-    median_phase<R, WIDTH>(myrow, lane, dev, dmax);
+    bool merged = false;
+    if constexpr (R == 64) {
+        // clean strip over the whole band: the merging median (median_merge.h)
+        if (!any_masked && C == 64 * R && p.debug_stop != 21) {
+            MergeMedian<R, WIDTH> mm;
+            mm.template run_lane<LY::RUN - R>(myrow + lane * LY::RUN, lane, dev, dmax);
+            merged = true;
+        }
+    }
+    if (!merged) median_phase<R, WIDTH>(myrow, lane, dev, dmax);
     stamp(3);
     // From here on the arguments are re-read from the kernarg segment (scalar loads):
     // keeping some 30 argument registers alive across the median phase would starve
@@ -144,7 +154,7 @@ static int launch_fused(hipStream_t s, const FusedParams &p)
     static bool attr_set = false;
     if (!attr_set) {
         KSP_CHECK(hipFuncSetAttribute((const void *)kern,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
         if (getenv("KSP_FUSED_DEBUG_OCC")) {
             int nb = -1;

@@ -4,6 +4,7 @@
 #pragma once
 #include <stdlib.h>
 
+#include "median_merge.h"
 #include "median_window.h"
 
 #ifndef FUSED_STRIP
@@ -162,8 +163,11 @@ __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int
 // sequence of loads -- rows past the end are clamped, their results dropped -- so the
 // hardware counters, not conservative waits at branch joins, pace the double buffer.
 // MODE is the input-flags mode, fixed per launch.
+// Returns whether this thread produced any amplitude that takes no part (NaN: flagged
+// or NaN input) -- amplitudes are non-negative, so their bit patterns order like
+// unsigned integers with the NaNs on top and one integer max per row keeps track.
 template <int R, int MODE>
-__device__ __forceinline__ void load_strip_fast(const FusedParams &p, float *lds, int b0, int tid)
+__device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds, int b0, int tid)
 {
     using LY = FusedLayout<R>;
     constexpr int LB = 4;
@@ -176,6 +180,7 @@ __device__ __forceinline__ void load_strip_fast(const FusedParams &p, float *lds
     const int bl = b0 + 2 * q;
     const float2 *vis = (const float2 *)p.vis + bl;
     const size_t stride = (size_t)p.vis_stride;
+    unsigned umax = 0;
     auto request = [&](float4 (&raw)[LB], unsigned (&fl)[LB], int rbase) {
 #pragma unroll
         for (int u = 0; u < LB; u++) {
@@ -201,6 +206,7 @@ __device__ __forceinline__ void load_strip_fast(const FusedParams &p, float *lds
                 if (fl[u] & 0xffu) a0 = __builtin_nanf("");
                 if (fl[u] >> 8) a1 = __builtin_nanf("");
             }
+            umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
             if (row < C) {
                 const int idx = LY::index(row);
                 lds[(2 * q) * LY::ROW + idx] = a0;
@@ -225,6 +231,7 @@ __device__ __forceinline__ void load_strip_fast(const FusedParams &p, float *lds
         lds[(2 * q) * LY::ROW + idx] = __builtin_nanf("");
         lds[(2 * q + 1) * LY::ROW + idx] = __builtin_nanf("");
     }
+    return umax > 0x7f800000u;
 }
 
 // ---------------------------------------------------------------------------------

@@ -256,6 +256,26 @@ class TestFused:
         assert np.isnan(out["noise"][0]) and np.isnan(out["noise"][1])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    def test_full_band_mixed_strips(self, context, command_queue, oracle):
+        """4096 channels (the shape that takes the merging median): strips with a NaN
+        visibility fall back to the sorted-window path, strips with infinite samples
+        stay on the merging path; band edges of the first and last lane in both."""
+        channels, baselines = 4096, 16
+        vis = inputs.add_rfi(inputs.generate_data(channels, baselines, seed=41), seed=42)
+        vis[100, 5] = np.nan
+        vis[0, 6] = np.nan + 1j
+        vis[4095, 7] = np.nan
+        vis[200, 9] = np.inf
+        vis[3, 10] = np.inf * 1j
+        vis[4090, 11] = np.inf
+        vis[:, 12] = 0
+        out = run_fused(make_template(context), command_queue, vis, n_sigma=11.0)
+        with np.errstate(all="ignore"):
+            ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, want_deviations=True)
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
     def test_unsupported_falls_back_to_sequence(self, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
