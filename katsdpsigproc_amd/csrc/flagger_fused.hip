@@ -45,7 +45,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     const int b0 = strip_of(blockIdx.x, p.n_strips) * FUSED_STRIP;
 
     // diagnostic time stamps (shader clock) of this wavefront's phases
-    unsigned long long *trace = p.trace ? p.trace + ((size_t)blockIdx.x * FUSED_STRIP + wave) * 8 : nullptr;
+    unsigned long long *trace = p.trace ? p.trace + ((size_t)blockIdx.x * FUSED_STRIP + wave) * 16 : nullptr;
     auto stamp = [&](int i) {
         if (trace != nullptr && lane == 0) trace[i] = __builtin_amdgcn_s_memtime();
     };
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         return;
     }
 
-    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, pa.debug_stop);
+    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, pa.debug_stop, trace);
     if (lane == 0 && pa.noise != nullptr && bl < pa.baselines) pa.noise[bl] = (float)noise64;
     stamp(4);
     if (pa.debug_stop == 3 || pa.debug_stop > 30) return;
@@ -177,7 +177,7 @@ static int launch_fused(hipStream_t s, const FusedParams &p)
     }
     // diagnostic run: collect per-wavefront phase time stamps and dump them
     FusedParams pt = p;
-    const size_t n = (size_t)p.n_strips * FUSED_STRIP * 8;
+    const size_t n = (size_t)p.n_strips * FUSED_STRIP * 16;
     KSP_CHECK(hipMalloc(&pt.trace, n * 8));
     KSP_CHECK(hipMemsetAsync(pt.trace, 0, n * 8, s));
     hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, pt);

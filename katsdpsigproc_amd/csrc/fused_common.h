@@ -163,6 +163,9 @@ __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int
 // sequence of loads -- rows past the end are clamped, their results dropped -- so the
 // hardware counters, not conservative waits at branch joins, pace the double buffer.
 // MODE is the input-flags mode, fixed per launch.
+#ifndef FUSED_LOAD_LB
+#define FUSED_LOAD_LB 4
+#endif
 // Returns whether this thread produced any amplitude that takes no part (NaN: flagged
 // or NaN input) -- amplitudes are non-negative, so their bit patterns order like
 // unsigned integers with the NaNs on top and one integer max per row keeps track.
@@ -170,7 +173,7 @@ template <int R, int MODE>
 __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds, int b0, int tid)
 {
     using LY = FusedLayout<R>;
-    constexpr int LB = 4;
+    constexpr int LB = FUSED_LOAD_LB;
     constexpr int LPR = FUSED_STRIP / 2;
     constexpr int RSTEP = FUSED_THREADS / LPR;
     constexpr int BATCH = RSTEP * LB;
@@ -214,15 +217,25 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
             }
         }
     };
-    float4 bufa[LB], bufb[LB];
-    unsigned fla[LB], flb[LB];
-    request(bufa, fla, 0);
-    for (int rb = 0; rb < C; rb += 2 * BATCH) {  // wave-uniform bounds
-        if (rb + BATCH < C) request(bufb, flb, rb + BATCH);
-        finish(bufa, fla, rb);
-        if (rb + BATCH < C) {
-            if (rb + 2 * BATCH < C) request(bufa, fla, rb + 2 * BATCH);
-            finish(bufb, flb, rb + BATCH);
+    // ring of NB batches: NB - 1 are in flight while one is turned into amplitudes
+#ifndef FUSED_LOAD_NB
+#define FUSED_LOAD_NB 3
+#endif
+    constexpr int NB = FUSED_LOAD_NB;
+    float4 buf[NB][LB];
+    unsigned fl[NB][LB];
+#pragma unroll
+    for (int k = 0; k < NB - 1; k++)
+        if (k * BATCH < C) request(buf[k], fl[k], k * BATCH);
+    for (int rb = 0; rb < C; rb += NB * BATCH) {  // wave-uniform bounds
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int cur = rb + k * BATCH;
+            if (cur < C) {
+                const int ahead = cur + (NB - 1) * BATCH;
+                if (ahead < C) request(buf[(k + NB - 1) % NB], fl[(k + NB - 1) % NB], ahead);
+                finish(buf[k], fl[k], cur);
+            }
         }
     }
     // channels C .. 64 R - 1 do not exist; the median phase expects NaN there
@@ -297,11 +310,13 @@ __device__ __forceinline__ void median_phase(const float *myrow, int lane, float
 // (fetch(c) returns the float32 amplitude, NaN if the sample is masked or outside the
 // band). Same arithmetic as MedianWindow::median(): median of the valid samples, even
 // counts averaged in float64. Used only for the handful of samples that decide a
-// result, so it favours simplicity: invalid -> +inf, odd-even transposition sort.
+// result: invalid -> +inf, insertion sort (k + 1 min/med3/max for the k-th sample).
 template <int WIDTH, class Fetch>
 __device__ __forceinline__ double exact_dev(int c, Fetch &&fetch)
 {
     constexpr int H = WIDTH / 2;
+    float pinf = __builtin_inff(), ninf = -__builtin_inff();
+    asm volatile("" : "+v"(pinf), "+v"(ninf));  // opaque: med3 with them stays one instruction
     float v[WIDTH];
     int n = 0;
 #pragma unroll
@@ -309,18 +324,21 @@ __device__ __forceinline__ double exact_dev(int c, Fetch &&fetch)
         const float a = fetch(c - H + k);
         const bool ok = a == a;
         n += ok;
-        v[k] = ok ? a : __builtin_inff();
+        const float x = ok ? a : pinf;
+        // insert x into the sorted v[0 .. k)
+        float out[WIDTH];
+        if (k == 0) {
+            out[0] = x;
+        } else {
+            out[0] = __builtin_amdgcn_fmed3f(v[0], x, ninf);  // min
+#pragma unroll
+            for (int i = 1; i < k; i++) out[i] = __builtin_amdgcn_fmed3f(v[i - 1], x, v[i]);
+            out[k] = __builtin_amdgcn_fmed3f(v[k - 1], x, pinf);  // max
+        }
+#pragma unroll
+        for (int i = 0; i <= k; i++) v[i] = out[i];
     }
     const float centre = fetch(c);
-#pragma unroll
-    for (int round = 0; round < WIDTH; round++) {
-#pragma unroll
-        for (int i = round & 1; i + 1 < WIDTH; i += 2) {
-            const float lo = fminf(v[i], v[i + 1]), hi = fmaxf(v[i], v[i + 1]);
-            v[i] = lo;
-            v[i + 1] = hi;
-        }
-    }
     float lo = v[0], hi = v[0];
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) {
@@ -477,56 +495,45 @@ __device__ __forceinline__ void rank_in_list(const double *list, int n, int r, i
     }
 }
 
-// Common case of the MAD's last step: the median's key bin holds n <= 64 samples.
-// `v` / `c` are one candidate per lane (|float32 deviation| and channel; lanes >= n
-// idle). Order statistics are located on the float32 values -- rounding is monotone,
-// so exact order refines float32 order -- and only the candidates whose float32 value
-// equals that of rank r (or r - 1) are recomputed in float64, all in ONE pass, one
-// candidate per lane. Returns the exact values of rank r (xk) and, when want_prev and
-// r >= 1, of rank r - 1 (prev).
-template <int WIDTH, class Fetch>
-__device__ __forceinline__ void rank_bin64(float v, int c, int n, int r, bool want_prev, int lane,
-                                           Fetch &&fetch, double &xk, double &prev)
+// Broadcast from a wave-uniform lane number: one v_readlane_b32 (the LDS-based
+// __shfl costs a ds_bpermute round trip each).
+__device__ __forceinline__ int ksp_bcast(int v, int src_lane)
+{
+    return __builtin_amdgcn_readlane(v, src_lane);
+}
+__device__ __forceinline__ float ksp_bcast(float v, int src_lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+__device__ __forceinline__ double ksp_bcast(double v, int src_lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
+// Common case of the MAD's last step: the median's key bin holds n <= 64 samples, one
+// per lane (x = exact |deviation|, lanes >= n idle). Each lane ranks its value against
+// the others by lane broadcast; returns the values of (stable) rank r and r - 1.
+__device__ __forceinline__ void rank_lanes64(double x, int n, int r, int lane, double &xk,
+                                             double &prev, bool &have_prev)
 {
     const bool live = lane < n;
-    int lt = 0, eq_before = 0;
+    int cnt = 0;
     for (int jj = 0; jj < n; jj++) {
-        const float y = __builtin_bit_cast(
-            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), jj));
-        lt += (y < v);
-        eq_before += (y == v) && (jj < lane);
+        const double y = ksp_bcast(x, jj);
+        cnt += (y < x) || (y == x && jj < lane);
     }
-    const int stable = lt + eq_before;
-    const int lane_r = __ffsll((long long)ksp_ballot(live && stable == r)) - 1;
-    const int lane_low =
-        (want_prev && r >= 1) ? __ffsll((long long)ksp_ballot(live && stable == r - 1)) - 1 : lane_r;
-    const float v_r = __shfl(v, lane_r, 64), v_low = __shfl(v, lane_low, 64);
-    const int below = __shfl(lt, lane_low, 64);  // candidates strictly below the tied set
-    const bool tied = live && (v == v_r || v == v_low);
-    const int c_any = __shfl(c, lane_r, 64);
-    const double x = fabs(exact_dev<WIDTH>(tied ? c : c_any, fetch));
-    // exact rank inside the tied set (usually one or two lanes)
-    int rs = below;
-    unsigned long long m = ksp_ballot(tied);
-    const int xlo = __double2loint(x), xhi = __double2hiint(x);
-    while (m) {
-        const int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const double y = __hiloint2double(__builtin_amdgcn_readlane(xhi, l),
-                                          __builtin_amdgcn_readlane(xlo, l));
-        rs += (y < x) || (y == x && l < lane);
-    }
-    xk = __shfl(x, __ffsll((long long)ksp_ballot(tied && rs == r)) - 1, 64);
-    prev = 0.0;
-    if (want_prev && r >= 1)
-        prev = __shfl(x, __ffsll((long long)ksp_ballot(tied && rs == r - 1)) - 1, 64);
+    xk = ksp_bcast(x, __ffsll((long long)ksp_ballot(live && cnt == r)) - 1);
+    have_prev = r >= 1;
+    prev = have_prev ? ksp_bcast(x, __ffsll((long long)ksp_ballot(live && cnt == r - 1)) - 1) : 0.0;
 }
 
 // `list` is this wavefront's private candidate list in LDS (LIST_CAP doubles).
 // Returns the float64 noise estimate (NaN when every deviation is zero).
 template <int R, int WIDTH, int LIST_CAP, class Fetch>
 __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, double *list,
-                                            Fetch &&fetch, int debug_stop = 0)
+                                            Fetch &&fetch, int debug_stop = 0,
+                                            unsigned long long *trace = nullptr)
 {
     constexpr int NP = R / 2;
     const int c0 = lane * R;
@@ -542,6 +549,10 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         kp[i] = __builtin_amdgcn_perm(__float_as_uint(dev[2 * i + 1]), __float_as_uint(dev[2 * i]),
                                       0x07060302u) & 0x7fff7fffu;
     }
+    auto stamp = [&](int i) {
+        if (trace != nullptr && lane == 0) trace[i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(8);
     if (debug_stop == 31) return (double)(zeros + kp[0] + kp[NP - 1]);
     const int total = 64 * R;
     if (zeros == total) return __builtin_nan("");  // numpy: median of nothing
@@ -561,6 +572,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
 #pragma unroll
         for (int i = 0; i < 32; i++) np[i] = kp[i] ^ 0x7fff7fffu;
         transpose_bits32(np);
+        stamp(9);
         eq0 = eq1 = 0xffffffffu;
 #pragma unroll
         for (int bit = 14; bit >= 0; bit--) {
@@ -584,6 +596,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         }
         in_bin = count_less16<NP>(kp, K + 1) - below_bin;
     }
+    stamp(10);
     if (debug_stop == 32) return (double)(K + below_bin);
     // (keys are re-derived from the deviations from here on: kp may die)
     auto key_of = [&](int j) -> unsigned { return (__float_as_uint(dev[j]) >> 16) & 0x7fffu; };
@@ -666,36 +679,39 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     if (!narrowed && in_bin <= 64) {
         // 3a. usual case: hand the bin's samples out one per lane (float32 value and
         //     channel go through the list), rank on float32, recompute only the ties
-        float *lv = (float *)list;
-        int *lc = (int *)list + 64;
+        int *lc = (int *)list;
         int n = 0;
-        unsigned any0 = 0xffffffffu, any1 = 0xffffffffu;  // sample slots with a hit in some lane
-        if constexpr (R == 64) {
-            any0 = ksp_wave_or_dpp(eq0);
-            any1 = ksp_wave_or_dpp(eq1);
-        }
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            if (!((((j & 1) ? any1 : any0) >> (j / 2)) & 1)) continue;  // scalar test
-            const bool hit = (R == 64) ? ((((j & 1) ? eq1 : eq0) >> (j / 2)) & 1) : (key_of(j) == K);
+        auto place = [&](bool hit, int channel) {
             const unsigned long long m = ksp_ballot(hit);
-            if (m) {
-                const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                if (hit) {
-                    lv[pos] = fabsf(dev[j]);
-                    lc[pos] = c0 + j;
-                }
-                n += __popcll(m);
+            const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (hit) lc[pos] = channel;
+            n += __popcll(m);
+        };
+        if constexpr (R == 64) {
+            // visit only the sample slots in which some lane has a hit (scalar loops)
+            for (unsigned any = ksp_wave_or_dpp(eq0); any != 0; any &= any - 1) {
+                const int i = __builtin_ctz(any);
+                place((eq0 >> i) & 1, c0 + 2 * i);
             }
+            for (unsigned any = ksp_wave_or_dpp(eq1); any != 0; any &= any - 1) {
+                const int i = __builtin_ctz(any);
+                place((eq1 >> i) & 1, c0 + 2 * i + 1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++) place(key_of(j) == K, c0 + j);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const float v = lane < n ? lv[lane] : 0.0f;
-        const int c = lane < n ? lc[lane] : 0;
-        if (debug_stop == 33) return (double)(v + c);
-        rank_bin64<WIDTH>(v, c, n, r, even, lane, fetch, xk, prev);
-        have_prev = r >= 1;
+        const int c = lc[lane < n ? lane : 0];
+        stamp(11);
+        if (debug_stop == 33) return (double)c;
+        // one exact recomputation serves every candidate (one per lane)
+        const double x = fabs(exact_dev<WIDTH>(c, fetch));
+        stamp(12);
+        rank_lanes64(x, n, r, lane, xk, prev, have_prev);
+        stamp(13);
         __builtin_amdgcn_wave_barrier();
     } else {
         // 3b. recompute all of the bin's samples exactly and rank them in float64

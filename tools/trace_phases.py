@@ -4,7 +4,8 @@
 import sys
 import numpy as np
 
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+a16 = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16)
+a = a16[:, :8]
 t = a[:, :7].astype(np.int64)
 hw = a[:, 7]
 ok = t[:, 0] > 0
@@ -16,6 +17,17 @@ d = np.diff(t, axis=1)
 print("waves:", len(t), " kernel span (cycles):", t[:, 6].max())
 for i, nme in enumerate(names):
     print(f"{nme:10s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
+if a16[:, 8:12].any():
+    okm = ok & (a16[:, 8] > 0) & (a16[:, 11] > 0)
+    m = a16[okm].astype(np.int64)
+    print("MAD split (mean cycles): keys+zeros %.0f, transpose %.0f, bit search %.0f, gather %.0f, rank+exact %.0f" % (
+        (m[:, 8] - m[:, 3]).mean(), (m[:, 9] - m[:, 8]).mean(), (m[:, 10] - m[:, 9]).mean(),
+        (m[:, 11] - m[:, 10]).mean(), (m[:, 4] - m[:, 11]).mean()))
+if a16[:, 12:14].any():
+    okm = ok & (a16[:, 12] > 0) & (a16[:, 13] > 0) & (a16[:, 11] > 0)
+    m = a16[okm].astype(np.int64)
+    print("rank+exact split: exact_dev %.0f, rank %.0f, rest of MAD %.0f" % (
+        (m[:, 12] - m[:, 11]).mean(), (m[:, 13] - m[:, 12]).mean(), (m[:, 4] - m[:, 13]).mean()))
 print("wave lifetime mean", (t[:, 6] - t[:, 0]).mean())
 # per CU: fraction of time in which k waves are in the load phase
 hwid = (hw & 0xffffffff).astype(np.int64)
