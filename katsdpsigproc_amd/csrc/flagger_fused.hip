@@ -88,12 +88,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     }
     if (!merged) median_phase<R, WIDTH>(myrow, lane, dev, dmax);
     stamp(3);
-    // From here on the arguments are re-read from the kernarg segment (scalar loads):
-    // keeping some 30 argument registers alive across the median phase would starve
-    // it of the scalar registers its lane masks live in.
-    const FusedParams *args = (const FusedParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(args));
-    const FusedParams &pa = *args;
+    const FusedParams &pa = p;
     if (pa.debug_stop == 2) {
         float acc = dmax;
 #pragma unroll
