@@ -48,12 +48,16 @@ struct FusedLayout {
 // blockIdx -> strip, XCD-aware: workgroups b, b+8, ... share an XCD, so the 8 strips
 // that make up one 512-byte input line / 64-byte output line are given to workgroups
 // of one XCD. Speed only -- any bijection is correct.
+#ifndef FUSED_XCD_GROUP
+#define FUSED_XCD_GROUP 8
+#endif
 __device__ __forceinline__ int strip_of(int id, int n_strips)
 {
-    const int full = (n_strips / 64) * 64;
+    constexpr int G = FUSED_XCD_GROUP;
+    const int full = (n_strips / (8 * G)) * (8 * G);
     if (id >= full) return id;
     const int xcd = id & 7, i = id >> 3;
-    return ((i >> 3) * 8 + xcd) * 8 + (i & 7);
+    return ((i / G) * 8 + xcd) * G + (i % G);
 }
 
 __device__ __forceinline__ float amp_with_flags(const FusedParams &p, float re, float im,

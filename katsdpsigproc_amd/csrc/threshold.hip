@@ -116,6 +116,32 @@ __global__ __launch_bounds__(256) void threshold_sum_kernel(
     const int j0 = t * VT;
     __syncthreads();
 
+    // Exact fast reject: thresholds are positive and every window's limit is w * thr_k,
+    // so if no sample of the chunk reaches min_k thr_k (with a 2^-20 margin that covers
+    // the rounding of the float64 sums) no window can fire and nothing is flagged. Data
+    // without interference takes this exit; the result is the same either way.
+    {
+        float thr_min = __builtin_inff();
+        bool thr_nan = false;
+        for (int k = 0; k < n_windows; k++) {
+            const float thr = __fmul_rn(t1, params.scales[k]);
+            thr_min = fminf(thr_min, thr);
+            thr_nan |= (thr != thr);
+        }
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < VT; i++) m = fmaxf(m, vals[j0 + i]);  // NaN samples never fire
+        const bool candidate = !(thr_min > 0.0f) || thr_nan || ((double)m >= (double)thr_min * (1.0 - 0x1p-20));
+        if (!__syncthreads_or(candidate && !thr_nan)) {
+            uint8_t *frow0 = flags + (size_t)bl * stride;
+            for (int j = t; j < TOT; j += 256) {
+                const int g = base + j;
+                if (j >= edge && j < edge + core && g < channels) frow0[g] = 0;
+            }
+            return;
+        }
+    }
+
     for (int k = 0; k < n_windows; k++) {
         const int w = 1 << k;
         const float thr = __fmul_rn(t1, params.scales[k]);
