@@ -541,31 +541,31 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
 {
     constexpr int NP = R / 2;
     const int c0 = lane * R;
-    // 1. 15-bit keys = float32 exponent + 7 mantissa bits of |dev|, two per register.
-    //    float32(|d|) is monotone in |d| and so is its truncation, hence the key bin of
-    //    the median can be found without knowing any exact value.
+    // 1. 15-bit keys, two per register: the top 16 bits of |dev|'s float32 pattern,
+    //    ROUNDED UP (key = (pattern + 0xffff) >> 16), so that key 0 means exactly zero
+    //    and the zeros can be counted from the bit planes below instead of with a
+    //    compare per sample. float32(|d|) is monotone in |d| and so is this rounding,
+    //    hence the key bin of the median can be found without knowing any exact value.
+    //    (Patterns above 0x7fff0000 -- NaN deviations only -- saturate at 0x7fff.)
     unsigned kp[NP];
-    int zeros = 0;  // wave-uniform: a compare mask per sample, counted on the scalar unit
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        zeros += __popcll(ksp_ballot(dev[2 * i] == 0.0f)) + __popcll(ksp_ballot(dev[2 * i + 1] == 0.0f));
-        // bytes 2,3 of each value side by side, sign bits cleared
-        kp[i] = __builtin_amdgcn_perm(__float_as_uint(dev[2 * i + 1]), __float_as_uint(dev[2 * i]),
-                                      0x07060302u) & 0x7fff7fffu;
+        const unsigned a = min((__float_as_uint(dev[2 * i]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu);
+        const unsigned b = min((__float_as_uint(dev[2 * i + 1]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu);
+        kp[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // bytes 2,3 of each, side by side
     }
+    int zeros;
+    if constexpr (R != 64) zeros = count_less16<NP>(kp, 1);
     auto stamp = [&](int i) {
         if (trace != nullptr && lane == 0) trace[i] = __builtin_amdgcn_s_memtime();
     };
     stamp(8);
-    if (debug_stop == 31) return (double)(zeros + kp[0] + kp[NP - 1]);
+    if (debug_stop == 31) return (double)(kp[0] + kp[NP - 1]);
     const int total = 64 * R;
-    if (zeros == total) return __builtin_nan("");  // numpy: median of nothing
-    const int rank2 = total + zeros;  // zeros sort first (reference rank.mako:261-266)
-    const int rank = rank2 / 2;       // rank of the (upper) median among all slots
-    const bool even = !(rank2 & 1);
     // 2. which key bin holds the median, and how many samples lie below the bin
     unsigned K = 0;
     int below_bin = 0, in_bin;
+    int rank2 = 0, rank = 0;  // zeros sort first (reference rank.mako:261-266): rank2 = total + zeros
     unsigned eq0 = 0, eq1 = 0;  // R == 64: which even / odd samples of the lane have key K
     if constexpr (R == 64) {
         // Bit-sliced search. The lane's 64 keys are transposed into 15 bit planes of
@@ -577,19 +577,70 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         for (int i = 0; i < 32; i++) np[i] = kp[i] ^ 0x7fff7fffu;
         transpose_bits32(np);
         stamp(9);
-        eq0 = eq1 = 0xffffffffu;
+        // samples with key 0 (= exact zeros): all 15 inverted planes set
+        {
+            unsigned z0 = np[0], z1 = np[16];
 #pragma unroll
-        for (int bit = 14; bit >= 0; bit--) {
-            const unsigned z0 = eq0 & np[bit], z1 = eq1 & np[16 + bit];  // bit clear: below
+            for (int b = 1; b < 15; b++) {
+                z0 &= np[b];
+                z1 &= np[16 + b];
+            }
+            zeros = ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
+        }
+        if (zeros == total) return __builtin_nan("");  // numpy: median of nothing
+        rank2 = total + zeros;
+        rank = rank2 / 2;
+        eq0 = eq1 = 0xffffffffu;
+        // two bits per step: the keys still matching the prefix split four ways by
+        // (bit1, bit0); three counts decide both bits after ONE round of reductions
+        auto step2 = [&](int hi, int lo) {
+            const unsigned a0 = eq0 & np[hi], a1 = eq1 & np[16 + hi];      // bit1 clear
+            const unsigned z00_0 = a0 & np[lo], z00_1 = a1 & np[16 + lo];  // 00
+            const unsigned z01_0 = a0 ^ z00_0, z01_1 = a1 ^ z00_1;         // 01
+            const unsigned b0 = eq0 ^ a0, b1 = eq1 ^ a1;                   // bit1 set
+            const unsigned z10_0 = b0 & np[lo], z10_1 = b1 & np[16 + lo];  // 10
+            const unsigned z11_0 = b0 ^ z10_0, z11_1 = b1 ^ z10_1;         // 11
+            const int packed = (__popc(z00_0) + __popc(z00_1)) | ((__popc(z01_0) + __popc(z01_1)) << 16);
+            const int s01 = ksp_wave_sum_dpp(packed);                      // each field <= 4096
+            const int c10 = ksp_wave_sum_dpp(__popc(z10_0) + __popc(z10_1));
+            const int n1 = below_bin + (s01 & 0xffff), n2 = n1 + (s01 >> 16), n3 = n2 + c10;
+            // the largest threshold with count(< threshold) <= rank
+            if (n3 <= rank) {
+                K |= (1u << hi) | (1u << lo);
+                below_bin = n3;
+                eq0 = z11_0;
+                eq1 = z11_1;
+            } else if (n2 <= rank) {
+                K |= 1u << hi;
+                below_bin = n2;
+                eq0 = z10_0;
+                eq1 = z10_1;
+            } else if (n1 <= rank) {
+                K |= 1u << lo;
+                below_bin = n1;
+                eq0 = z01_0;
+                eq1 = z01_1;
+            } else {
+                eq0 = z00_0;
+                eq1 = z00_1;
+            }
+        };
+#pragma unroll
+        for (int bit = 14; bit >= 2; bit -= 2) step2(bit, bit - 1);
+        {
+            const unsigned z0 = eq0 & np[0], z1 = eq1 & np[16];  // last bit on its own
             const int c = below_bin + ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
-            const bool take = c <= rank;  // wave-uniform: the median's key has this bit set
-            K |= take ? (1u << bit) : 0u;
+            const bool take = c <= rank;
+            K |= take ? 1u : 0u;
             below_bin = take ? c : below_bin;
             eq0 = take ? (eq0 ^ z0) : z0;
             eq1 = take ? (eq1 ^ z1) : z1;
         }
         in_bin = ksp_wave_sum_dpp(__popc(eq0) + __popc(eq1));
     } else {
+        if (zeros == total) return __builtin_nan("");
+        rank2 = total + zeros;
+        rank = rank2 / 2;
         for (int bit = 14; bit >= 0; bit--) {
             const unsigned test = K | (1u << bit);
             const int c = count_less16<NP>(kp, test);
@@ -600,10 +651,13 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         }
         in_bin = count_less16<NP>(kp, K + 1) - below_bin;
     }
+    const bool even = !(rank2 & 1);
     stamp(10);
     if (debug_stop == 32) return (double)(K + below_bin);
     // (keys are re-derived from the deviations from here on: kp may die)
-    auto key_of = [&](int j) -> unsigned { return (__float_as_uint(dev[j]) >> 16) & 0x7fffu; };
+    auto key_of = [&](int j) -> unsigned {
+        return min((__float_as_uint(dev[j]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu) >> 16;
+    };
     auto bin_mask = [&](unsigned key) -> unsigned long long {
         unsigned long long m = 0;
 #pragma unroll
@@ -618,19 +672,22 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         // Degenerate data (hundreds of samples in one key bin, e.g. quantised input):
         // narrow the bin with an exact search on the full float32 patterns, which
         // leaves only samples whose float32 deviations are identical.
-        unsigned cur = K << 16;
+        // (key K >= 1 covers the patterns ((K - 1) << 16) + 1 .. K << 16)
+        const unsigned first = ((K - 1) << 16) + 1u;
+        unsigned offs = 0;
         int below = below_bin;
         for (int bit = 15; bit >= 0; bit--) {
-            const unsigned test = cur | (1u << bit);
+            const unsigned test = first + (offs | (1u << bit));
             int c = 0;
 #pragma unroll
             for (int j = 0; j < R; j++) c += (__float_as_uint(dev[j]) & 0x7fffffffu) < test;
             c = ksp_wave_sum(c);
             if (c <= rank) {
-                cur = test;
+                offs |= 1u << bit;
                 below = c;
             }
         }
+        const unsigned cur = first + offs;
         cand = 0;
 #pragma unroll
         for (int j = 0; j < R; j++)

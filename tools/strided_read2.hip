@@ -86,6 +86,11 @@ int main(int argc, char **argv)
     const int K76 = 76 * 1024, K136 = 136 * 1024;
     run<2, 8, 256>("actual (strip 4, 2 blk/CU)", vis, out, C, B, 0, 8, 0, K76);
     run<2, 4, 256>("depth 4", vis, out, C, B, 0, 8, 0, K76);
+    run<4, 4, 256>("strip 8, 256 threads, 2 blk/CU, depth 4", vis, out, C, B, 0, 8, 0, K76);
+    run<4, 8, 256>("strip 8, 256 threads, 2 blk/CU, depth 8", vis, out, C, B, 0, 8, 0, K76);
+    run<4, 2, 256>("strip 8, 256 threads, 2 blk/CU, depth 2", vis, out, C, B, 0, 8, 0, K76);
+    run<8, 4, 256>("strip 16, 256 threads, 2 blk/CU, depth 4", vis, out, C, B, 0, 8, 0, K76);
+    run<8, 8, 256>("strip 16, 256 threads, 2 blk/CU, depth 8", vis, out, C, B, 0, 8, 0, K76);
     run<2, 4, 256>("depth 4 + prefetch 1 round ahead", vis, out, C, B, 0, 8, 0, K76, 1);
     run<2, 4, 256>("depth 4 + prefetch 2 rounds ahead", vis, out, C, B, 0, 8, 0, K76, 2);
     run<2, 4, 256>("depth 4 + prefetch 3 rounds ahead", vis, out, C, B, 0, 8, 0, K76, 3);
