@@ -13,6 +13,7 @@
 // Numerics (reference rfi/host.py:157-163 on float32 input): numpy.median stays in
 // float32 -- even count -> float32(a + b) * 0.5 -- and the 1.4826 scale is applied
 // in float64; the float32 output is that float64 product rounded once.
+#include "bitplane.h"
 #include "rank.h"
 
 #define KSP_MAD_NORMAL 1.4826
@@ -45,6 +46,163 @@ __global__ __launch_bounds__(KSP_RANK_THREADS) void madnz_t_kernel(const float *
     float med = block_select(v, rank2 / 2, !(rank2 & 1), &scratch);
     if (zeros == channels) med = __builtin_nanf("");  // numpy: median of nothing
     if (t == 0) noise[bl] = (float)((double)med * KSP_MAD_NORMAL);
+}
+
+// ----------------------------------------------------------------------------
+// madnz_t for rows of up to 4096 channels: ONE WAVEFRONT per baseline, lane l holds
+// channels [64 l, 64 l + 64) (256 contiguous bytes per lane, 16 KiB per wavefront).
+// The 31-bit patterns of |x| are transposed into 31 bit planes of 64 bits per lane
+// (two in-register 32 x 32 bit transposes), after which one step of the bit-wise
+// rank search is a few ANDs and population counts per lane plus DPP wave reductions
+// -- two bits per step, no LDS, no barriers -- instead of a compare per value and a
+// workgroup reduction per bit.
+template <class PlaneFn>
+struct PlaneSearch {
+    unsigned eq0 = 0xffffffffu, eq1 = 0xffffffffu;  // even / odd values still matching the prefix
+    unsigned prefix = 0;                            // bits decided so far
+    int below = 0;                                  // values (whole row) below the prefix
+    int rank;
+    PlaneFn plane;  // plane(bit, half) -> INVERTED plane (bit clear), half 0 = even values
+
+    __device__ __forceinline__ PlaneSearch(int rank_, PlaneFn plane_) : rank(rank_), plane(plane_) {}
+
+    template <int HI, int LO>
+    __device__ __forceinline__ void step2()
+    {
+        const unsigned a0 = eq0 & plane(HI, 0), a1 = eq1 & plane(HI, 1);
+        const unsigned z00_0 = a0 & plane(LO, 0), z00_1 = a1 & plane(LO, 1);
+        const unsigned z01_0 = a0 ^ z00_0, z01_1 = a1 ^ z00_1;
+        const unsigned b0 = eq0 ^ a0, b1 = eq1 ^ a1;
+        const unsigned z10_0 = b0 & plane(LO, 0), z10_1 = b1 & plane(LO, 1);
+        const unsigned z11_0 = b0 ^ z10_0, z11_1 = b1 ^ z10_1;
+        const int packed = (__popc(z00_0) + __popc(z00_1)) | ((__popc(z01_0) + __popc(z01_1)) << 16);
+        const int s01 = ksp_wave_sum_dpp(packed);
+        const int c10 = ksp_wave_sum_dpp(__popc(z10_0) + __popc(z10_1));
+        const int n1 = below + (s01 & 0xffff), n2 = n1 + (s01 >> 16), n3 = n2 + c10;
+        if (n3 <= rank) {
+            prefix |= (1u << HI) | (1u << LO);
+            below = n3;
+            eq0 = z11_0;
+            eq1 = z11_1;
+        } else if (n2 <= rank) {
+            prefix |= 1u << HI;
+            below = n2;
+            eq0 = z10_0;
+            eq1 = z10_1;
+        } else if (n1 <= rank) {
+            prefix |= 1u << LO;
+            below = n1;
+            eq0 = z01_0;
+            eq1 = z01_1;
+        } else {
+            eq0 = z00_0;
+            eq1 = z00_1;
+        }
+    }
+
+    template <int BIT>
+    __device__ __forceinline__ void step1()
+    {
+        const unsigned z0 = eq0 & plane(BIT, 0), z1 = eq1 & plane(BIT, 1);
+        const int c = below + ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
+        const bool take = c <= rank;
+        prefix |= take ? (1u << BIT) : 0u;
+        below = take ? c : below;
+        eq0 = take ? (eq0 ^ z0) : z0;
+        eq1 = take ? (eq1 ^ z1) : z1;
+    }
+};
+
+__global__ __launch_bounds__(256) void madnz_t_wave_kernel(const float *__restrict__ in,
+                                                           float *__restrict__ noise, int channels,
+                                                           int baselines, int stride, int vec_ok)
+{
+    const int lane = threadIdx.x & 63;
+    const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bl >= baselines) return;  // whole wavefronts leave together
+    const float *row = in + (size_t)bl * stride + lane * 64;
+    // |x| patterns; channels that do not exist get the largest pattern and are never
+    // reached because ranks are taken among `channels` values
+    unsigned u[64];
+    if (vec_ok && lane * 64 + 64 <= channels) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint4 q = *(const uint4 *)(row + 4 * i);
+            u[4 * i] = q.x & 0x7fffffffu;
+            u[4 * i + 1] = q.y & 0x7fffffffu;
+            u[4 * i + 2] = q.z & 0x7fffffffu;
+            u[4 * i + 3] = q.w & 0x7fffffffu;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            u[i] = (lane * 64 + i < channels) ? (__float_as_uint(row[i]) & 0x7fffffffu) : 0x7fffffffu;
+    }
+    // inverted bit planes: hi[b] / hi[16 + b] = bit 16 + b of the even / odd values
+    // clear; lo[...] likewise for bits 0..15
+    unsigned hi[32], lo[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        hi[i] = ~__builtin_amdgcn_perm(u[2 * i + 1], u[2 * i], 0x07060302u);
+        lo[i] = ~__builtin_amdgcn_perm(u[2 * i + 1], u[2 * i], 0x05040100u);
+    }
+    transpose_bits32(hi);
+    transpose_bits32(lo);
+    auto plane = [&](int bit, int half) -> unsigned {
+        return bit >= 16 ? hi[16 * half + bit - 16] : lo[16 * half + bit];
+    };
+    // zeros: every one of the 31 bits clear
+    unsigned z0 = lo[0], z1 = lo[16];
+#pragma unroll
+    for (int b = 1; b < 16; b++) {
+        z0 &= lo[b];
+        z1 &= lo[16 + b];
+    }
+#pragma unroll
+    for (int b = 0; b < 15; b++) {
+        z0 &= hi[b];
+        z1 &= hi[16 + b];
+    }
+    const int zeros = ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
+    // zeros sort first, so the median of the non-zero values has rank
+    // (channels + zeros) / 2 in the whole row (reference rank.mako:261-266)
+    const int rank2 = channels + zeros;
+    const int rank = rank2 / 2;
+    PlaneSearch<decltype(plane)> search(rank, plane);
+    search.template step2<30, 29>();
+    search.template step2<28, 27>();
+    search.template step2<26, 25>();
+    search.template step2<24, 23>();
+    search.template step2<22, 21>();
+    search.template step2<20, 19>();
+    search.template step2<18, 17>();
+    search.template step2<16, 15>();
+    search.template step2<14, 13>();
+    search.template step2<12, 11>();
+    search.template step2<10, 9>();
+    search.template step2<8, 7>();
+    search.template step2<6, 5>();
+    search.template step2<4, 3>();
+    search.template step2<2, 1>();
+    search.template step1<0>();
+    const unsigned pat = search.prefix;  // pattern of the value of rank `rank`
+    float result = __uint_as_float(pat);
+    if (!(rank2 & 1)) {
+        // even count: also the value of rank - 1 -- the same value if it occurs below
+        // rank as well, else the largest value below it
+        float prev = result;
+        if (search.below == rank) {
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < 64; i++) m = max(m, u[i] < pat ? u[i] : 0u);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+            prev = __uint_as_float(m);
+        }
+        result = __fmul_rn(__fadd_rn(result, prev), 0.5f);
+    }
+    if (zeros == channels) result = __builtin_nanf("");  // numpy: median of nothing
+    if (lane == 0) noise[bl] = (float)((double)result * KSP_MAD_NORMAL);
 }
 
 // Channel-major variant: workgroup = 64 baselines x 16 channel phases.
@@ -116,6 +274,13 @@ extern "C" int ksp_madnz_t(int device, void *stream, const float *in, float *noi
     if (baselines == 0) return 0;
     KSP_CHECK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
+    if (channels > 1024 && channels <= 4096) {
+        const int vec_ok = (stride % 4 == 0) && ((uintptr_t)in % 16 == 0);
+        hipLaunchKernelGGL(madnz_t_wave_kernel, dim3(ksp_divup(baselines, 4)), dim3(256), 0, s, in,
+                           noise, channels, baselines, stride, vec_ok);
+        KSP_LAUNCH_CHECK();
+        return 0;
+    }
     const int vt = ksp_divup(channels, KSP_RANK_THREADS);
 #define KSP_MT(VT)                                                                             \
     hipLaunchKernelGGL(madnz_t_kernel<VT>, dim3(baselines), dim3(KSP_RANK_THREADS), 0, s, in, \

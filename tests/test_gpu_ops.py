@@ -229,7 +229,8 @@ class TestBackground:
 
 class TestNoiseEst:
     @pytest.mark.parametrize("kind", ["MAD", "MADT"])
-    @pytest.mark.parametrize("shape", [(117, 273), (4096, 40), (1000, 3), (2, 5)])
+    @pytest.mark.parametrize("shape", [(117, 273), (4096, 40), (1000, 3), (2, 5), (4095, 9),
+                                       (1025, 5), (2500, 7)])  # fmt: skip
     def test_result(self, kind, shape, context, command_queue, oracle):
         # reference test/rfi/test_noise_est.py:54-79; exact instead of rtol 1e-7
         from katsdpsigproc_amd.rfi import device
@@ -259,6 +260,27 @@ class TestNoiseEst:
         ):
             out = device.NoiseEstHostFromDevice(template, command_queue)(dev)
             np.testing.assert_allclose(expected, out, rtol=1e-7)
+
+    @pytest.mark.parametrize("channels", [300, 2048, 4096, 3001])
+    def test_ties_and_zeros(self, channels, context, command_queue, oracle):
+        """Quantised data (many equal values, even and odd counts), all-zero and
+        single-value columns: the rank search must land on the right duplicates."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(channels)
+        dev = (rs.randint(-3, 4, (channels, 12)) * 0.5).astype(np.float32)
+        dev[:, 0] = 0.0
+        dev[:, 1] = 0.0
+        dev[7, 1] = -2.5
+        dev[:, 2] = 1.25
+        dev[:, 3] = rs.randint(0, 2, channels).astype(np.float32) * 3.0
+        dev[:, 4] = np.where(np.arange(channels) % 2 == 0, 1e-45, -1e38).astype(np.float32)
+        for template in (device.NoiseEstMADDeviceTemplate(context),
+                         device.NoiseEstMADTDeviceTemplate(context, 10240)):  # fmt: skip
+            out = device.NoiseEstHostFromDevice(template, command_queue)(dev)
+            with np.errstate(all="ignore"):
+                expected = oracle.NoiseEstMADHost()(dev)
+            np.testing.assert_array_equal(expected.astype(np.float32), out)
 
     def test_max_channels(self, context, command_queue):
         from katsdpsigproc_amd.rfi import device
