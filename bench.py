@@ -112,6 +112,24 @@ def measured_traffic(channels, baselines, use_flags, args):
     return None
 
 
+class _StdoutToStderr:
+    """Route file descriptor 1 to stderr for a while: RCCL prints a version banner on
+    stdout when the first communicator is created, and stdout must carry exactly one
+    JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -135,14 +153,21 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
     torch = None
-    if world > 1:
+    # KSP_BENCH_FORCE_DIST=1 exercises the torch.distributed code path with a single
+    # rank too (used to rehearse the multi-GPU path on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("KSP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))  # fmt: skip
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))  # fmt: skip
+            # create the communicator now (its banner goes to stderr with the redirect)
+            dist.barrier()
 
     from katsdpsigproc_amd import accel, hip
     from katsdpsigproc_amd.rfi import device
@@ -151,14 +176,14 @@ def main() -> None:
     if not devices:
         raise SystemExit("no HIP device: this benchmark needs an MI355X (no CPU fallback)")
     context = devices[local_rank if world > 1 else 0].make_context()
-    if world > 1:
+    if use_dist:
         # run on torch's current stream so the RCCL broadcast orders with the kernel
         queue = hip.CommandQueue(context, stream=torch.cuda.current_stream().cuda_stream)
     else:
         queue = context.create_command_queue()
 
     channels, baselines = args.channels, args.baselines
-    use_flags = device.BackgroundFlags.CHANNEL if world > 1 else device.BackgroundFlags.NONE
+    use_flags = device.BackgroundFlags.CHANNEL if use_dist else device.BackgroundFlags.NONE
     template = device.FlaggerDeviceTemplate(
         device.BackgroundMedianFilterDeviceTemplate(context, WIDTH, use_flags=use_flags),
         device.NoiseEstMADTDeviceTemplate(context, 10240),
@@ -174,7 +199,7 @@ def main() -> None:
     fn.buffer("vis").set(queue, vis)
     del vis
     mask_tensor = None
-    if world > 1:
+    if use_dist:
         # the channel mask lives in the flagger's input_flags buffer; rank 0 owns the
         # truth and RCCL broadcasts it every step (4 KiB over xGMI)
         mask = (np.random.RandomState(2).random_sample(channels) < 1.0 / 16.0).astype(np.uint8)
@@ -254,7 +279,7 @@ def main() -> None:
                 "use_flags": use_flags.name,
                 "keep_deviations": bool(args.keep_deviations),
                 "sharding": f"baselines over {world} GPU(s)"
-                            + (", RCCL broadcast of the channel mask per step" if world > 1 else ""),
+                            + (", RCCL broadcast of the channel mask per step" if use_dist else ""),
             },
             "roofline": {
                 "bound": "hbm",
