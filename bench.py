@@ -198,23 +198,54 @@ def main() -> None:
     vis = synth_block(channels, baselines, seed=1 + rank)
     fn.buffer("vis").set(queue, vis)
     del vis
-    mask_tensor = None
+    pipe = None
     if use_dist:
-        # the channel mask lives in the flagger's input_flags buffer; rank 0 owns the
-        # truth and RCCL broadcasts it every step (4 KiB over xGMI)
+        # The channel mask is rank 0's to decide and changes from block to block in a
+        # live system, so every step broadcasts it (4 KiB, RCCL over xGMI). The broadcast
+        # for step k + 1 runs on its own stream while step k's kernel is busy: two mask
+        # buffers alternate under the flagger's input_flags slot, events order
+        # "broadcast into buffer i" before "kernel reads buffer i" before the next
+        # broadcast into it.
         mask = (np.random.RandomState(2).random_sample(channels) < 1.0 / 16.0).astype(np.uint8)
-        buf = fn.buffer("input_flags")
-        mask_tensor = torch.as_tensor(buf.buffer, device=f"cuda:{local_rank}")
-        if rank == 0:
-            buf.set(queue, mask)
-        else:
-            buf.zero(queue)
+        first = fn.buffer("input_flags")
+        second = accel.DeviceArray(context, first.shape, first.dtype, first.padded_shape)
+        bufs = [first, second]
+        for buf in bufs:
+            if rank == 0:
+                buf.set(queue, mask)
+            else:
+                buf.zero(queue)
         queue.finish()
+        dev_t = torch.device("cuda", local_rank)
+        pipe = {
+            "bufs": bufs,
+            "tensors": [torch.as_tensor(b.buffer, device=dev_t) for b in bufs],
+            "ready": [torch.cuda.Event(), torch.cuda.Event()],  # broadcast into buffer i done
+            "free": [torch.cuda.Event(), torch.cuda.Event()],   # kernel reading buffer i done
+            "comm": torch.cuda.Stream(device=dev_t),
+            "compute": torch.cuda.current_stream(),
+            "k": 0,
+        }
+        with torch.cuda.stream(pipe["comm"]):
+            dist.broadcast(pipe["tensors"][0], src=0)
+            pipe["ready"][0].record(pipe["comm"])
+        pipe["free"][1].record(pipe["compute"])
 
     def step() -> None:
-        if mask_tensor is not None:
-            dist.broadcast(mask_tensor, src=0)
+        if pipe is None:
+            fn()
+            return
+        i = pipe["k"] % 2
+        j = 1 - i
+        pipe["k"] += 1
+        pipe["compute"].wait_event(pipe["ready"][i])
+        fn.bind(input_flags=pipe["bufs"][i])
         fn()
+        pipe["free"][i].record(pipe["compute"])
+        with torch.cuda.stream(pipe["comm"]):
+            pipe["comm"].wait_event(pipe["free"][j])  # the kernel that last read buffer j
+            dist.broadcast(pipe["tensors"][j], src=0)
+            pipe["ready"][j].record(pipe["comm"])
 
     def sync() -> None:
         queue.finish()
