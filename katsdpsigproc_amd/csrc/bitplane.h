@@ -34,3 +34,69 @@ __device__ __forceinline__ void transpose_bits32(unsigned (&a)[32])
     }
 }
 
+
+// Bit-wise rank search on bit planes. The values of a row are spread over the lanes of
+// one wavefront, 64 per lane, and transposed so that plane(bit, half) is a 32-bit mask
+// over the lane's even (half 0) / odd (half 1) values with the bit CLEAR. The search
+// walks from the top bit down keeping, per lane, which values still match the prefix
+// (eq0/eq1) and, for the row, how many values lie below the prefix; each step decides
+// one or two bits from population counts reduced over the wavefront with DPP.
+// Afterwards `prefix` is the key of (0-based) rank `rank`, `below` the number of values
+// strictly below it.
+template <class PlaneFn>
+struct PlaneSearch {
+    unsigned eq0 = 0xffffffffu, eq1 = 0xffffffffu;  // even / odd values still matching the prefix
+    unsigned prefix = 0;                            // bits decided so far
+    int below = 0;                                  // values (whole row) below the prefix
+    int rank;
+    PlaneFn plane;  // plane(bit, half) -> INVERTED plane (bit clear), half 0 = even values
+
+    __device__ __forceinline__ PlaneSearch(int rank_, PlaneFn plane_) : rank(rank_), plane(plane_) {}
+
+    template <int HI, int LO>
+    __device__ __forceinline__ void step2()
+    {
+        const unsigned a0 = eq0 & plane(HI, 0), a1 = eq1 & plane(HI, 1);
+        const unsigned z00_0 = a0 & plane(LO, 0), z00_1 = a1 & plane(LO, 1);
+        const unsigned z01_0 = a0 ^ z00_0, z01_1 = a1 ^ z00_1;
+        const unsigned b0 = eq0 ^ a0, b1 = eq1 ^ a1;
+        const unsigned z10_0 = b0 & plane(LO, 0), z10_1 = b1 & plane(LO, 1);
+        const unsigned z11_0 = b0 ^ z10_0, z11_1 = b1 ^ z10_1;
+        const int packed = (__popc(z00_0) + __popc(z00_1)) | ((__popc(z01_0) + __popc(z01_1)) << 16);
+        const int s01 = ksp_wave_sum_dpp(packed);
+        const int c10 = ksp_wave_sum_dpp(__popc(z10_0) + __popc(z10_1));
+        const int n1 = below + (s01 & 0xffff), n2 = n1 + (s01 >> 16), n3 = n2 + c10;
+        if (n3 <= rank) {
+            prefix |= (1u << HI) | (1u << LO);
+            below = n3;
+            eq0 = z11_0;
+            eq1 = z11_1;
+        } else if (n2 <= rank) {
+            prefix |= 1u << HI;
+            below = n2;
+            eq0 = z10_0;
+            eq1 = z10_1;
+        } else if (n1 <= rank) {
+            prefix |= 1u << LO;
+            below = n1;
+            eq0 = z01_0;
+            eq1 = z01_1;
+        } else {
+            eq0 = z00_0;
+            eq1 = z00_1;
+        }
+    }
+
+    template <int BIT>
+    __device__ __forceinline__ void step1()
+    {
+        const unsigned z0 = eq0 & plane(BIT, 0), z1 = eq1 & plane(BIT, 1);
+        const int c = below + ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
+        const bool take = c <= rank;
+        prefix |= take ? (1u << BIT) : 0u;
+        below = take ? c : below;
+        eq0 = take ? (eq0 ^ z0) : z0;
+        eq1 = take ? (eq1 ^ z1) : z1;
+    }
+};
+

@@ -10,6 +10,7 @@
 // re^2+im^2 and is only 1e-6-close (reference test/test_percentile.py:86-90).
 // HBM-bound at 4 (8 for complex) bytes per element once the search is hidden by
 // other resident workgroups.
+#include "bitplane.h"
 #include "rank.h"
 
 template <int VT, bool IS_AMP>
@@ -50,10 +51,105 @@ __global__ __launch_bounds__(KSP_RANK_THREADS) void percentile5_kernel(
     }
 }
 
+__device__ __forceinline__ float key_to_float(unsigned k)
+{
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+// ----------------------------------------------------------------------------
+// Rows of 1025 .. 4096 columns: ONE WAVEFRONT per row, lane l holds columns
+// [64 l, 64 l + 64) of the range. Values become 32-bit keys that order like the floats
+// (sign bit flipped for positive, all bits for negative values), the keys are
+// transposed into 32 bit planes per lane, and the three order statistics come from
+// three bit-plane searches (bitplane.h) -- no LDS, no barriers.
+template <bool IS_AMP>
+__global__ __launch_bounds__(256) void percentile5_wave_kernel(const void *__restrict__ in,
+                                                               float *__restrict__ out, int rows,
+                                                               int in_stride, int out_stride,
+                                                               int first_col, int n_cols)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // whole wavefronts leave together
+    const size_t base = (size_t)row * in_stride + first_col + lane * 64;
+    unsigned key[64];
+    unsigned kmin = 0xffffffffu, kmax = 0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        unsigned k = 0xffffffffu;  // columns beyond the range: above every real key
+        if (lane * 64 + i < n_cols) {
+            float a;
+            if (IS_AMP)
+                a = ((const float *)in)[base + i];
+            else {
+                const float2 z = ((const float2 *)in)[base + i];
+                a = ksp_abs_c64(z.x, z.y);
+            }
+            const unsigned u = __float_as_uint(a);
+            k = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+        key[i] = k;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, off, 64));
+    }
+    unsigned hi[32], lo[32];  // inverted planes of key bits 16..31 / 0..15
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        hi[i] = ~__builtin_amdgcn_perm(key[2 * i + 1], key[2 * i], 0x07060302u);
+        lo[i] = ~__builtin_amdgcn_perm(key[2 * i + 1], key[2 * i], 0x05040100u);
+    }
+    transpose_bits32(hi);
+    transpose_bits32(lo);
+    auto plane = [&](int bit, int half) __attribute__((always_inline)) -> unsigned {
+        return bit >= 16 ? hi[16 * half + bit - 16] : lo[16 * half + bit];
+    };
+    auto select = [&](int rank) __attribute__((always_inline)) -> float {
+        PlaneSearch<decltype(plane)> s(rank, plane);
+        s.template step2<31, 30>();
+        s.template step2<29, 28>();
+        s.template step2<27, 26>();
+        s.template step2<25, 24>();
+        s.template step2<23, 22>();
+        s.template step2<21, 20>();
+        s.template step2<19, 18>();
+        s.template step2<17, 16>();
+        s.template step2<15, 14>();
+        s.template step2<13, 12>();
+        s.template step2<11, 10>();
+        s.template step2<9, 8>();
+        s.template step2<7, 6>();
+        s.template step2<5, 4>();
+        s.template step2<3, 2>();
+        s.template step2<1, 0>();
+        return key_to_float(s.prefix);
+    };
+    const float p25 = select((n_cols - 1) / 4);
+    const float p75 = select(((n_cols - 1) * 3) / 4);
+    const float p50 = select((n_cols - 1) / 2);
+    if (lane == 0) {
+        out[0 * (size_t)out_stride + row] = key_to_float(kmin);
+        out[1 * (size_t)out_stride + row] = key_to_float(kmax);
+        out[2 * (size_t)out_stride + row] = p25;
+        out[3 * (size_t)out_stride + row] = p75;
+        out[4 * (size_t)out_stride + row] = p50;
+    }
+}
+
 template <bool IS_AMP>
 static int launch_percentile(hipStream_t s, const void *in, float *out, int rows, int in_stride,
                              int out_stride, int first_col, int n_cols)
 {
+    if (n_cols > 1024 && n_cols <= 4096) {
+        hipLaunchKernelGGL((percentile5_wave_kernel<IS_AMP>), dim3(ksp_divup(rows, 4)), dim3(256), 0, s,
+                           in, out, rows, in_stride, out_stride, first_col, n_cols);
+        KSP_LAUNCH_CHECK();
+        return 0;
+    }
     const int vt = ksp_divup(n_cols, KSP_RANK_THREADS);
 #define KSP_P5(VT)                                                                              \
     hipLaunchKernelGGL((percentile5_kernel<VT, IS_AMP>), dim3(rows), dim3(KSP_RANK_THREADS), 0, \

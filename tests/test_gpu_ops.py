@@ -130,6 +130,27 @@ class TestPercentile5:
             expected = np.percentile(ary[:, lo:hi], [0, 100, 25, 75, 50], axis=1, method="lower")
             np.testing.assert_array_equal(expected.astype(np.float32), out)
 
+    @pytest.mark.parametrize("C", [700, 2000, 4096])
+    def test_percentile5_ties_and_signs(self, C, context, command_queue):
+        """Heavily tied and signed float32 input (numpy's "lower" percentile is defined for
+        any order; the reference kernel only promises positive values)."""
+        from katsdpsigproc_amd import percentile
+
+        rs = np.random.RandomState(C)
+        ary = (rs.randint(-4, 5, (9, C)) * 0.25).astype(np.float32)
+        ary[0] = 0.0
+        ary[1] = -1.5
+        ary[2, ::2] = -0.0
+        if C <= 1024:
+            ary = np.abs(ary)  # narrow rows use the reference's positive-values search
+        fn = percentile.Percentile5Template(context, max_columns=5000).instantiate(command_queue, (9, C))
+        fn.ensure_all_bound()
+        fn.buffer("src").set(command_queue, ary)
+        fn()
+        out = fn.buffer("dest").get(command_queue)
+        expected = np.percentile(ary, [0, 100, 25, 75, 50], axis=1, method="lower").astype(np.float32)
+        np.testing.assert_array_equal(expected, out)
+
     def test_errors(self, context, command_queue):
         from katsdpsigproc_amd import percentile
 
