@@ -11,7 +11,9 @@
 //
 // Numerics follow the host class (reference rfi/host.py:133-151): amplitude is
 // numpy's complex64 abs in float32; median and subtraction are float64; the
-// float32 output is the rounded float64 deviation; masked samples give 0.
+// float32 output is the rounded float64 deviation (SortedWindow::deviation: one
+// float32 subtraction when the window holds an odd number of valid samples, which
+// gives the same bits); masked samples give 0.
 // HBM-bound: 8 B read + 4 B written per sample (+ WIDTH-1 halo rows per segment).
 #include "median_window.h"
 
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void background_kernel(
         return a;
     };
 
-    MedianWindow<WIDTH> win;
+    SortedWindow<WIDTH> win;
     win.reset();
     float ring[WIDTH];
 #pragma unroll
@@ -76,13 +78,16 @@ __global__ __launch_bounds__(256) void background_kernel(
         for (int k = 0; k < WIDTH; k++) {
             const int c = base + k;  // entering sample
             if (c < last) {          // wave-uniform
-                win.step(ring[k], cur[k]);
+                float leaving = ring[k];
+                asm("" : "+v"(leaving));  // opaque: do not carry the entry-time mask along
+                win.step(leaving, leaving == leaving, cur[k], cur[k] == cur[k]);
                 ring[k] = cur[k];
                 const int oc = c - H;  // output channel
                 if (oc >= c_begin) {   // wave-uniform; oc < c_end holds since c < last
-                    const float xc = ring[(k + WIDTH - H) % WIDTH];
-                    float d = 0.0f;
-                    if (xc == xc) d = (float)((double)xc - win.median());
+                    float xc = ring[(k + WIDTH - H) % WIDTH];
+                    asm("" : "+v"(xc));
+                    float d = win.deviation(xc);
+                    d = (xc == xc) ? d : 0.0f;
                     if (active) out[(size_t)oc * stride + b] = d;
                 }
             }
