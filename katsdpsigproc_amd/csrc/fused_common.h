@@ -313,7 +313,7 @@ __device__ __forceinline__ void median_phase(const float *myrow, int lane, float
 
 // Exact float64 deviation of channel c, recomputed from the amplitudes of its window
 // (fetch(c) returns the float32 amplitude, NaN if the sample is masked or outside the
-// band). Same arithmetic as MedianWindow::median(): median of the valid samples, even
+// band). Same arithmetic as SortedWindow::deviation(): median of the valid samples, even
 // counts averaged in float64. Used only for the handful of samples that decide a
 // result: invalid -> +inf, insertion sort (k + 1 min/med3/max for the k-th sample).
 template <int WIDTH, class Fetch>

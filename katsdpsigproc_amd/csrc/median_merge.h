@@ -17,7 +17,7 @@
 // Samples that do not exist (beyond the band, first and last lane only) are +-inf in
 // alternation away from the band edge, which keeps #(+inf) - #(-inf) in {0, 1} for
 // every window; with one more +inf the number of valid samples is even and the median
-// is the float64 mean of ranks H - 1 and H, as in MedianWindow. Any OTHER masked
+// is the float64 mean of ranks H - 1 and H, as in SortedWindow. Any OTHER masked
 // sample (flagged, NaN) would need a rank that varies per lane: callers use the
 // sorted-window path for such data.
 #pragma once

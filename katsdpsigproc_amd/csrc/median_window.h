@@ -14,72 +14,17 @@
 // 1. The valid samples then sit centred in the sorted array: with an odd number of
 // valid samples the median is s[H]; with an even number it is the mean of s[H-1]
 // and s[H] (computed in float64 like pandas does). No padding ever needs to
-// change sides: see step().
+// change sides: a leaving padding is taken from the side that is ahead, an entering
+// one goes to the side that is behind.
+//
+// That invariant leaves ONE bit of state per lane: `odd` = "one more +inf than -inf"
+// (equivalently: the number of valid samples is even). A lane-boolean lives in a
+// scalar register pair as a wavefront mask, so updating it is scalar-unit work and
+// the vector unit only runs the compares/selects of the sorted array itself. The
+// caller supplies, next to each leaving/entering sample, whether it takes part.
 #pragma once
 #include "ksp_common.h"
 
-template <int WIDTH>
-struct MedianWindow {
-    static constexpr int H = WIDTH / 2;
-    float s[WIDTH];  // sorted ascending
-    int n_neg;       // paddings stored as -inf
-    int n_pos;       // paddings stored as +inf
-
-    __device__ __forceinline__ void reset()
-    {
-#pragma unroll
-        for (int i = 0; i < WIDTH; i++) s[i] = i < H ? -__builtin_inff() : __builtin_inff();
-        n_neg = H;
-        n_pos = H + 1;
-    }
-
-    // Replace `out` (the sample that leaves; NaN if it was padding) by `in` (NaN if
-    // the entering sample is invalid).
-    __device__ __forceinline__ void step(float out, float in)
-    {
-        const float inf = __builtin_inff();
-        const bool out_valid = out == out;
-        const bool in_valid = in == in;
-        // A leaving padding is taken from the +inf side when that side is ahead,
-        // otherwise from the -inf side; either keeps 0 <= n_pos - n_neg <= 1.
-        const bool take_pos = n_pos > n_neg;
-        const float vo = out_valid ? out : (take_pos ? inf : -inf);
-        n_pos -= (!out_valid && take_pos);
-        n_neg -= (!out_valid && !take_pos);
-        const bool give_pos = n_pos == n_neg;
-        const float vi = in_valid ? in : (give_pos ? inf : -inf);
-        n_pos += (!in_valid && give_pos);
-        n_neg += (!in_valid && !give_pos);
-
-        float L[WIDTH - 1];
-#pragma unroll
-        for (int i = 0; i < WIDTH - 1; i++) L[i] = (s[i] < vo) ? s[i] : s[i + 1];
-        s[0] = fminf(L[0], vi);
-#pragma unroll
-        for (int i = 1; i < WIDTH - 1; i++) s[i] = __builtin_amdgcn_fmed3f(L[i - 1], vi, L[i]);
-        s[WIDTH - 1] = fmaxf(L[WIDTH - 2], vi);
-    }
-
-    __device__ __forceinline__ int n_valid() const { return WIDTH - n_neg - n_pos; }
-
-    // Median of the valid samples, as float64 (requires n_valid() >= 1).
-    __device__ __forceinline__ double median() const
-    {
-        const double hi = (double)s[H];
-        if (WIDTH == 1) return hi;
-        const double lo = (double)s[H > 0 ? H - 1 : 0];
-        return (n_pos == n_neg) ? hi : (lo + hi) * 0.5;
-    }
-};
-
-// ---------------------------------------------------------------------------------
-// Same sorted window, with the padding bookkeeping reduced to ONE boolean per lane.
-// The invariant 0 <= #(+inf) - #(-inf) <= 1 means the two counters of MedianWindow
-// carry a single bit of state: `odd` = "one more +inf than -inf" (equivalently: the
-// number of valid samples is even). A lane-boolean lives in a scalar register pair as
-// a wavefront mask, so updating it is scalar-unit work and the vector unit only runs
-// the compares/selects of the sorted array itself. The caller supplies, next to each
-// leaving/entering sample, whether it is padding (flagged, NaN or out of band).
 template <int WIDTH>
 struct SortedWindow {
     static constexpr int H = WIDTH / 2;
