@@ -29,6 +29,8 @@
 #include "fused_common.h"
 #include <hip/hip_ext.h>
 
+#include <atomic>
+
 // Events armed by ksp_flagger_fused_profile for the NEXT fused launch of this thread.
 static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
 
 // =================================================================================
 template <int R, int WIDTH>
-static int launch_fused(hipStream_t s, const FusedParams &p)
+static int launch_fused(int device, hipStream_t s, const FusedParams &p)
 {
     using LY = FusedLayout<R>;
     const size_t lds_bytes = LY::LDS_BYTES;
@@ -146,11 +148,13 @@ static int launch_fused(hipStream_t s, const FusedParams &p)
     KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
                              s));
     auto kern = flagger_fused_kernel<R, WIDTH>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the opt-in to more than 64 KiB of dynamic LDS is per device (one context per
+    // device in one process is a supported arrangement, reference doc/user/init.rst:4-6)
+    static std::atomic<bool> attr_set[64];
+    if (device < 0 || device >= 64 || !attr_set[device].load(std::memory_order_acquire)) {
         KSP_CHECK(hipFuncSetAttribute((const void *)kern,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
+        if (device >= 0 && device < 64) attr_set[device].store(true, std::memory_order_release);
         if (getenv("KSP_FUSED_DEBUG_OCC")) {
             int nb = -1;
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FUSED_THREADS, lds_bytes);
@@ -261,7 +265,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
         p.scales[k] = (scales64 != nullptr && k < n_windows) ? scales64[k] : 0.0;
 
     hipStream_t s = (hipStream_t)stream;
-    if (channels <= 64 * 4) return launch_fused<4, 13>(s, p);
-    if (channels <= 64 * 16) return launch_fused<16, 13>(s, p);
-    return launch_fused<64, 13>(s, p);
+    if (channels <= 64 * 4) return launch_fused<4, 13>(device, s, p);
+    if (channels <= 64 * 16) return launch_fused<16, 13>(device, s, p);
+    return launch_fused<64, 13>(device, s, p);
 }

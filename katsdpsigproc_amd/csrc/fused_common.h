@@ -168,8 +168,14 @@ __device__ __forceinline__ void load_strip(const FusedParams &p, float *lds, int
 // sequence of loads -- rows past the end are clamped, their results dropped -- so the
 // hardware counters, not conservative waits at branch joins, pace the double buffer.
 // MODE is the input-flags mode, fixed per launch.
+// Loader geometry (measured best on MI355X: more loads in flight per lane make the
+// 32-byte pattern slower, fewer leave the wavefront waiting): a ring of FUSED_LOAD_NB
+// batches of FUSED_LOAD_LB rows per lane.
 #ifndef FUSED_LOAD_LB
 #define FUSED_LOAD_LB 4
+#endif
+#ifndef FUSED_LOAD_NB
+#define FUSED_LOAD_NB 3
 #endif
 // Returns whether this thread produced any amplitude that takes no part (NaN: flagged
 // or NaN input) -- amplitudes are non-negative, so their bit patterns order like
@@ -223,9 +229,6 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
         }
     };
     // ring of NB batches: NB - 1 are in flight while one is turned into amplitudes
-#ifndef FUSED_LOAD_NB
-#define FUSED_LOAD_NB 3
-#endif
     constexpr int NB = FUSED_LOAD_NB;
     float4 buf[NB][LB];
     unsigned fl[NB][LB];
