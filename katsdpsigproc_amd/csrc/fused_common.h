@@ -722,14 +722,22 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             n += __popcll(m);
         };
         if constexpr (R == 64) {
-            // visit only the sample slots in which some lane has a hit (scalar loops)
-            for (unsigned any = ksp_wave_or_dpp(eq0); any != 0; any &= any - 1) {
-                const int i = __builtin_ctz(any);
-                place((eq0 >> i) & 1, c0 + 2 * i);
-            }
-            for (unsigned any = ksp_wave_or_dpp(eq1); any != 0; any &= any - 1) {
-                const int i = __builtin_ctz(any);
-                place((eq1 >> i) & 1, c0 + 2 * i + 1);
+            // every lane knows its own hits (eq0 / eq1); a prefix sum over the lanes
+            // gives each lane its first slot in the list and the lanes fill in their
+            // (zero to a few) channels on their own -- no per-sample wave operations
+            const int mine = __popc(eq0) + __popc(eq1);
+            const int incl = ksp_wave_scan_dpp(mine);
+            n = __builtin_amdgcn_readlane(incl, 63);
+            int pos = incl - mine;
+            unsigned h0 = eq0, h1 = eq1;
+            while (h0 | h1) {  // divergent: as many rounds as the busiest lane has hits
+                if (h0) {
+                    lc[pos++] = c0 + 2 * (__ffs((int)h0) - 1);
+                    h0 &= h0 - 1;
+                } else {
+                    lc[pos++] = c0 + 2 * (__ffs((int)h1) - 1) + 1;
+                    h1 &= h1 - 1;
+                }
             }
         } else {
 #pragma unroll

@@ -91,6 +91,19 @@ __device__ __forceinline__ int ksp_wave_sum_dpp(int v)
     v += KSP_DPP(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
 }
+// Inclusive prefix sum over the lanes of a wavefront (DPP scan: shifts within the
+// rows of 16, then the row totals carried across with row_bcast:15 / row_bcast:31).
+__device__ __forceinline__ int ksp_wave_scan_dpp(int v)
+{
+    v += KSP_DPP(v, 0x111, 0xf);  // row_shr:1
+    v += KSP_DPP(v, 0x112, 0xf);  // row_shr:2
+    v += KSP_DPP(v, 0x114, 0xf);  // row_shr:4
+    v += KSP_DPP(v, 0x118, 0xf);  // row_shr:8  -> inclusive scan inside each row
+    v += KSP_DPP(v, 0x142, 0xa);  // rows 1, 3 += total of rows 0, 2
+    v += KSP_DPP(v, 0x143, 0xc);  // rows 2, 3 += total of rows 0..1
+    return v;
+}
+
 __device__ __forceinline__ unsigned ksp_wave_or_dpp(unsigned u)
 {
     int v = (int)u;
