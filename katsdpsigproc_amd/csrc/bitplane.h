@@ -62,29 +62,18 @@ struct PlaneSearch {
         const unsigned b0 = eq0 ^ a0, b1 = eq1 ^ a1;
         const unsigned z10_0 = b0 & plane(LO, 0), z10_1 = b1 & plane(LO, 1);
         const unsigned z11_0 = b0 ^ z10_0, z11_1 = b1 ^ z10_1;
-        const int packed = (__popc(z00_0) + __popc(z00_1)) | ((__popc(z01_0) + __popc(z01_1)) << 16);
-        const int s01 = ksp_wave_sum_dpp(packed);
-        const int c10 = ksp_wave_sum_dpp(__popc(z10_0) + __popc(z10_1));
+        int s01 = (__popc(z00_0) + __popc(z00_1)) | ((__popc(z01_0) + __popc(z01_1)) << 16);
+        int c10 = __popc(z10_0) + __popc(z10_1);
+        ksp_wave_sum2_dpp(s01, c10);  // each field <= 4096
         const int n1 = below + (s01 & 0xffff), n2 = n1 + (s01 >> 16), n3 = n2 + c10;
-        if (n3 <= rank) {
-            prefix |= (1u << HI) | (1u << LO);
-            below = n3;
-            eq0 = z11_0;
-            eq1 = z11_1;
-        } else if (n2 <= rank) {
-            prefix |= 1u << HI;
-            below = n2;
-            eq0 = z10_0;
-            eq1 = z10_1;
-        } else if (n1 <= rank) {
-            prefix |= 1u << LO;
-            below = n1;
-            eq0 = z01_0;
-            eq1 = z01_1;
-        } else {
-            eq0 = z00_0;
-            eq1 = z00_1;
-        }
+        // the two bits are the number of thresholds with count(< threshold) <= rank
+        // (n1 <= n2 <= n3); selected without branches
+        static_assert(HI == LO + 1, "adjacent bits");
+        const bool g1 = n1 <= rank, g2 = n2 <= rank, g3 = n3 <= rank;
+        prefix |= (unsigned)((int)g1 + (int)g2 + (int)g3) << LO;
+        below = g3 ? n3 : g2 ? n2 : g1 ? n1 : below;
+        eq0 = g3 ? z11_0 : g2 ? z10_0 : g1 ? z01_0 : z00_0;
+        eq1 = g3 ? z11_1 : g2 ? z10_1 : g1 ? z01_1 : z00_1;
     }
 
     template <int BIT>

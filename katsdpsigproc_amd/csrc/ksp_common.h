@@ -91,6 +91,26 @@ __device__ __forceinline__ int ksp_wave_sum_dpp(int v)
     v += KSP_DPP(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
 }
+// Two wavefront sums at once: the two DPP chains are interleaved so that each
+// instruction fills the wait states the other chain needs between dependent DPP steps.
+__device__ __forceinline__ void ksp_wave_sum2_dpp(int &a, int &b)
+{
+    a += KSP_DPP(a, 0x111, 0xf);
+    b += KSP_DPP(b, 0x111, 0xf);
+    a += KSP_DPP(a, 0x112, 0xf);
+    b += KSP_DPP(b, 0x112, 0xf);
+    a += KSP_DPP(a, 0x114, 0xf);
+    b += KSP_DPP(b, 0x114, 0xf);
+    a += KSP_DPP(a, 0x118, 0xf);
+    b += KSP_DPP(b, 0x118, 0xf);
+    a += KSP_DPP(a, 0x142, 0xa);
+    b += KSP_DPP(b, 0x142, 0xa);
+    a += KSP_DPP(a, 0x143, 0xc);
+    b += KSP_DPP(b, 0x143, 0xc);
+    a = __builtin_amdgcn_readlane(a, 63);
+    b = __builtin_amdgcn_readlane(b, 63);
+}
+
 // Inclusive prefix sum over the lanes of a wavefront (DPP scan: shifts within the
 // rows of 16, then the row totals carried across with row_bcast:15 / row_bcast:31).
 __device__ __forceinline__ int ksp_wave_scan_dpp(int v)
