@@ -68,7 +68,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     stamp(1);
     const bool any_masked = __syncthreads_or(masked);
     stamp(2);
-    if (p.debug_stop == 1) return;
+    if (p.debug_stop == 1 || p.debug_stop == 11) return;
 
     const int bl = b0 + wave;
     float *myrow = lds + wave * LY::ROW;

@@ -212,8 +212,14 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
 #pragma unroll
         for (int u = 0; u < LB; u++) {
             const int row = rbase + r0 + u * RSTEP;
-            float a0 = ksp_abs_c64(raw[u].x, raw[u].y);
-            float a1 = ksp_abs_c64(raw[u].z, raw[u].w);
+            float a0, a1;
+            if (p.debug_stop == 11) {  // diagnostic: how long does the loader take without arithmetic?
+                a0 = raw[u].x;
+                a1 = raw[u].z;
+            } else {
+                a0 = ksp_abs_c64(raw[u].x, raw[u].y);
+                a1 = ksp_abs_c64(raw[u].z, raw[u].w);
+            }
             if (MODE == KSP_FLAGS_CHANNEL) {
                 if (fl[u]) a0 = a1 = __builtin_nanf("");
             } else if (MODE == KSP_FLAGS_FULL) {

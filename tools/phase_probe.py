@@ -31,7 +31,7 @@ if use_flags == device.BackgroundFlags.CHANNEL:
 elif use_flags == device.BackgroundFlags.FULL:
     fn.buffer("input_flags").set(q, (rs.random_sample((channels, baselines)) < 1 / 16).astype(np.uint8))
 names = {11: "load-noamp", 1: "load", 2: "+median", 31: "+keys", 32: "+bitsearch", 33: "+gather", 34: "+rank", 35: "+below", 36: "+noise64", 3: "+mad", 4: "+threshold", 0: "full"}
-for stop in (1, 2, 31, 32, 33, 3, 4, 0):
+for stop in (1, 11, 1, 2, 31, 32, 33, 3, 4, 0):
     os.environ["KSP_FUSED_DEBUG_STOP"] = str(stop)
     fn(); q.finish()
     a = q.enqueue_marker()
