@@ -276,6 +276,53 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @pytest.mark.parametrize("mode", ["none", "channel"])
+    def test_degenerate_full_band(self, mode, context, command_queue, oracle):
+        """4096 channels (bit-plane MAD, merging or sorted-window median): all-zero and
+        constant baselines, heavily quantised data (hundreds of samples per key bin, ties at
+        the median rank, even and odd counts), denormal-sized deviations, one huge outlier."""
+        rs = np.random.RandomState(8)
+        channels, baselines = 4096, 12
+        vis = inputs.generate_data(channels, baselines, seed=51)
+        vis[:, 0] = 0
+        vis[:, 1] = 3 + 4j
+        vis[:, 2] = (rs.randint(0, 4, channels) + 0j).astype(np.complex64)
+        vis[:, 3] = (rs.randint(0, 50, channels) * 0.25 + 0j).astype(np.complex64)
+        vis[100, 3] = 1000.0
+        vis[:, 4] = (rs.randint(0, 3, channels) * 1e-42 + 0j).astype(np.complex64)
+        vis[:, 5] = (rs.randint(0, 1000, channels) * 2.0 ** -10 + 0j).astype(np.complex64)
+        vis[::2, 6] = vis[1::2, 6]  # pairs of equal samples
+        vis[:, 7] = (np.arange(channels) % 7 + 1j * (np.arange(channels) % 5)).astype(np.complex64)
+        fl = None
+        if mode == "channel":
+            fl = (rs.random_sample(channels) < 1 / 16).astype(np.uint8)
+        out = run_fused(make_template(context, mode.upper()), command_queue, vis, fl, n_sigma=11.0)
+        with np.errstate(all="ignore"):
+            ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, fl, want_deviations=True)
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
+    @pytest.mark.parametrize("seed", [1, 2, 3])
+    def test_full_band_interference_kinds(self, seed, context, command_queue, oracle):
+        """4096 channels with narrow-band, broad-band (runs of 2-12 channels: windows 2, 4
+        and 8 of SumThreshold fire) and weak interference just around the thresholds."""
+        rs = np.random.RandomState(seed)
+        channels, baselines = 4096, 20
+        vis = inputs.generate_data(channels, baselines, seed=60 + seed)
+        for b in range(baselines):
+            for _ in range(12):
+                c = rs.randint(0, channels - 12)
+                w = rs.randint(1, 13)
+                vis[c:c + w, b] += rs.uniform(2.0, 9.0) * np.exp(2j * np.pi * rs.rand())
+            vis[rs.randint(0, channels, 5), b] *= rs.uniform(20, 60)
+        out = run_fused(make_template(context), command_queue, vis, n_sigma=5.0 + seed)
+        ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, n_sigma=5.0 + seed, want_deviations=True)
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        assert ref_flags.sum() > 0
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
     def test_unsupported_falls_back_to_sequence(self, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
