@@ -48,9 +48,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source and link the shared library; returns its path."""
     hipcc = _hipcc()
     extra = os.environ.get("KSP_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
-    if extra:
-        force = True
     os.makedirs(OUT_DIR, exist_ok=True)
+    # objects built with other flags (an experiment's -D...) must not be reused
+    stamp = os.path.join(OUT_DIR, ".flags")
+    flags_now = " ".join(FLAGS + extra)
+    try:
+        with open(stamp) as f:
+            flags_before = f.read()
+    except OSError:
+        flags_before = None
+    if flags_before != flags_now:
+        force = True
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
         os.path.join(HERE, "..", "include", "katsdpsigproc_hip.h")
@@ -75,6 +83,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(pool.map(run, jobs))
     if jobs or force or _stale(OUT, objects):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objects)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return OUT
 
 
