@@ -9,7 +9,7 @@ from .abc import AbstractCommandQueue, AbstractContext
 
 
 class TransposeTemplate:
-    """Transpose a 2-D array of any 1/2/4/8-byte element type.
+    """Transpose a 2-D array of any 1/2/4/8/16-byte element type.
 
     Parameters
     ----------
@@ -32,7 +32,7 @@ class TransposeTemplate:
         self.context = context
         self.dtype = np.dtype(dtype)
         self.ctype = ctype
-        if self.dtype.itemsize not in (1, 2, 4, 8):
+        if self.dtype.itemsize not in (1, 2, 4, 8, 16):
             raise ValueError(f"unsupported element size {self.dtype.itemsize}")
         if tuning is None:
             tuning = self.autotune(context, dtype, ctype)

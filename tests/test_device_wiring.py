@@ -172,8 +172,9 @@ def test_primitive_ops(context, queue):
     assert fn.slots["dest"].shape == (81, 53)
     fn()
     assert [int(a) for a in queue.launches[-1][1][2:]] == [53, 81, 64, 96, 4]
+    transpose.TransposeTemplate(context, np.complex128, "double2")  # 16-byte elements are fine
     with pytest.raises(ValueError):
-        transpose.TransposeTemplate(context, np.complex128, "double2")
+        transpose.TransposeTemplate(context, np.dtype([("a", "u1", 3)]), "uchar3")
     p = percentile.Percentile5Template(context, max_columns=5000)
     with pytest.raises(ValueError):
         p.instantiate(queue, (10, 100), (5, 5))

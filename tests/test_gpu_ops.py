@@ -51,7 +51,7 @@ def unpack(bits, shape):
 # ------------------------------------------------------------------------ primitives
 class TestTranspose:
     @pytest.mark.parametrize("R, C", [(4, 5), (53, 7), (53, 81), (32, 64), (1000, 333)])
-    @pytest.mark.parametrize("dtype", [np.float32, np.uint8, np.complex64, np.int16])
+    @pytest.mark.parametrize("dtype", [np.float32, np.uint8, np.complex64, np.int16, np.complex128])
     def test_padded(self, R, C, dtype, context, command_queue):
         # reference test/test_transpose.py:35-59
         from katsdpsigproc_amd import transpose
