@@ -13,6 +13,8 @@
 // Numerics (reference rfi/host.py:157-163 on float32 input): numpy.median stays in
 // float32 -- even count -> float32(a + b) * 0.5 -- and the 1.4826 scale is applied
 // in float64; the float32 output is that float64 product rounded once.
+#include <atomic>
+
 #include "bitplane.h"
 #include "rank.h"
 
@@ -56,31 +58,11 @@ __global__ __launch_bounds__(KSP_RANK_THREADS) void madnz_t_kernel(const float *
 // rank search is a few ANDs and population counts per lane plus DPP wave reductions
 // -- two bits per step, no LDS, no barriers -- instead of a compare per value and a
 // workgroup reduction per bit.
-__global__ __launch_bounds__(256) void madnz_t_wave_kernel(const float *__restrict__ in,
-                                                           float *__restrict__ noise, int channels,
-                                                           int baselines, int stride, int vec_ok)
+// The search itself: u[64] are the lane's 64 |x| patterns (0x7fffffff for channels that
+// do not exist); returns the float32 median of the non-zero values of the row (NaN if
+// there are none), identical in every lane.
+__device__ __forceinline__ float wave_median_nonzero(const unsigned (&u)[64], int channels)
 {
-    const int lane = threadIdx.x & 63;
-    const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (bl >= baselines) return;  // whole wavefronts leave together
-    const float *row = in + (size_t)bl * stride + lane * 64;
-    // |x| patterns; channels that do not exist get the largest pattern and are never
-    // reached because ranks are taken among `channels` values
-    unsigned u[64];
-    if (vec_ok && lane * 64 + 64 <= channels) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint4 q = *(const uint4 *)(row + 4 * i);
-            u[4 * i] = q.x & 0x7fffffffu;
-            u[4 * i + 1] = q.y & 0x7fffffffu;
-            u[4 * i + 2] = q.z & 0x7fffffffu;
-            u[4 * i + 3] = q.w & 0x7fffffffu;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 64; i++)
-            u[i] = (lane * 64 + i < channels) ? (__float_as_uint(row[i]) & 0x7fffffffu) : 0x7fffffffu;
-    }
     // inverted bit planes: hi[b] / hi[16 + b] = bit 16 + b of the even / odd values
     // clear; lo[...] likewise for bits 0..15
     unsigned hi[32], lo[32];
@@ -145,6 +127,92 @@ __global__ __launch_bounds__(256) void madnz_t_wave_kernel(const float *__restri
         result = __fmul_rn(__fadd_rn(result, prev), 0.5f);
     }
     if (zeros == channels) result = __builtin_nanf("");  // numpy: median of nothing
+    return result;
+}
+
+__global__ __launch_bounds__(256) void madnz_t_wave_kernel(const float *__restrict__ in,
+                                                           float *__restrict__ noise, int channels,
+                                                           int baselines, int stride, int vec_ok)
+{
+    const int lane = threadIdx.x & 63;
+    const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bl >= baselines) return;  // whole wavefronts leave together
+    const float *row = in + (size_t)bl * stride + lane * 64;
+    // |x| patterns; channels that do not exist get the largest pattern and are never
+    // reached because ranks are taken among `channels` values
+    unsigned u[64];
+    if (vec_ok && lane * 64 + 64 <= channels) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint4 q = *(const uint4 *)(row + 4 * i);
+            u[4 * i] = q.x & 0x7fffffffu;
+            u[4 * i + 1] = q.y & 0x7fffffffu;
+            u[4 * i + 2] = q.z & 0x7fffffffu;
+            u[4 * i + 3] = q.w & 0x7fffffffu;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            u[i] = (lane * 64 + i < channels) ? (__float_as_uint(row[i]) & 0x7fffffffu) : 0x7fffffffu;
+    }
+    const float result = wave_median_nonzero(u, channels);
+    if (lane == 0) noise[bl] = (float)((double)result * KSP_MAD_NORMAL);
+}
+
+// madnz (channel-major input) for up to 4096 channels: a 512-thread workgroup brings a
+// strip of 8 adjacent baselines x all channels into LDS (32-byte row segments, the
+// layout of the fused flagger: [baseline][channel], lane runs padded by 4 words), then
+// each of its 8 wavefronts runs the bit-plane search on its baseline. One pass over the
+// data instead of the 33 of the per-bit re-reading kernel below.
+#define MADNZ_STRIP 8
+#define MADNZ_RUN 68                        // 64 channels + 4 words of padding per lane
+#define MADNZ_ROW (64 * MADNZ_RUN + 8)      // words per baseline
+__global__ __launch_bounds__(64 * MADNZ_STRIP) void madnz_strip_kernel(
+    const float *__restrict__ in, float *__restrict__ noise, int channels, int baselines, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) float img[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * MADNZ_STRIP;
+    // cooperative load: 2 lanes x 16 B per row, 256 rows per pass
+    const int q = tid & 1, r0 = tid >> 1;
+    const int bq = b0 + 4 * q;
+    const bool vec = (stride % 4 == 0) && ((size_t)in % 16 == 0) && (bq + 4 <= baselines);
+    for (int row = r0; row < 4096; row += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < channels) {
+            const float *src = in + (size_t)row * stride + bq;
+            if (vec) {
+                v = *(const float4 *)src;
+            } else {
+                if (bq < baselines) v.x = src[0];
+                if (bq + 1 < baselines) v.y = src[1];
+                if (bq + 2 < baselines) v.z = src[2];
+                if (bq + 3 < baselines) v.w = src[3];
+            }
+        }
+        const int idx = (row >> 6) * MADNZ_RUN + (row & 63);
+        img[(4 * q + 0) * MADNZ_ROW + idx] = v.x;
+        img[(4 * q + 1) * MADNZ_ROW + idx] = v.y;
+        img[(4 * q + 2) * MADNZ_ROW + idx] = v.z;
+        img[(4 * q + 3) * MADNZ_ROW + idx] = v.w;
+    }
+    __syncthreads();
+    const int bl = b0 + wave;
+    if (bl >= baselines) return;  // whole wavefronts leave together
+    const float *run = img + wave * MADNZ_ROW + lane * MADNZ_RUN;
+    unsigned u[64];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint4 w = *(const uint4 *)(run + 4 * i);
+        u[4 * i] = w.x & 0x7fffffffu;
+        u[4 * i + 1] = w.y & 0x7fffffffu;
+        u[4 * i + 2] = w.z & 0x7fffffffu;
+        u[4 * i + 3] = w.w & 0x7fffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+        if (lane * 64 + i >= channels) u[i] = 0x7fffffffu;
+    const float result = wave_median_nonzero(u, channels);
     if (lane == 0) noise[bl] = (float)((double)result * KSP_MAD_NORMAL);
 }
 
@@ -263,6 +331,20 @@ extern "C" int ksp_madnz(int device, void *stream, const float *in, float *noise
     KSP_REQUIRE(channels > 0 && baselines >= 0 && stride >= baselines, "bad shape");
     if (baselines == 0) return 0;
     KSP_CHECK(hipSetDevice(device));
+    if (channels <= 4096) {
+        const size_t lds = sizeof(float) * MADNZ_STRIP * MADNZ_ROW;
+        static std::atomic<bool> attr_set[64];
+        if (device < 0 || device >= 64 || !attr_set[device].load(std::memory_order_acquire)) {
+            KSP_CHECK(hipFuncSetAttribute((const void *)madnz_strip_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (device >= 0 && device < 64) attr_set[device].store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(madnz_strip_kernel, dim3(ksp_divup(baselines, MADNZ_STRIP)),
+                           dim3(64 * MADNZ_STRIP), lds, (hipStream_t)stream, in, noise, channels,
+                           baselines, stride);
+        KSP_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(madnz_kernel, dim3(ksp_divup(baselines, 64)), dim3(64 * MADNZ_PHASES), 0,
                        (hipStream_t)stream, in, noise, channels, baselines, stride);
     KSP_LAUNCH_CHECK();
