@@ -269,27 +269,12 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
 // whose exact float64 value decides a result are recomputed on demand (exact_dev).
 // The LDS row holds NaN for every sample that must not take part (flagged, NaN input,
 // channels >= C); channels outside [0, 64 R) are never read.
-template <int R, int WIDTH>
-__device__ __forceinline__ void median_phase(const float *myrow, int lane, float (&dev)[R],
-                                             float &dmax)
+// General form: the samples are supplied by `amp_rel(i)`, -H <= i < R + H (NaN = takes
+// no part, including everything beyond the band).
+template <int R, int WIDTH, class Src>
+__device__ __forceinline__ void median_phase_src(Src &&amp_rel, float (&dev)[R], float &dmax)
 {
-    using LY = FusedLayout<R>;
     constexpr int H = WIDTH / 2;
-    const float *run = myrow + lane * LY::RUN;
-    const float nan = __builtin_nanf("");
-    // amplitude of channel lane*R + i, -H <= i < R + H. When the window reaches no
-    // further than the neighbouring lanes' runs, which sit RUN = R + 4 words away,
-    // every address is `run` plus a constant.
-    auto amp_rel = [&](int i) -> float {
-        if (i >= 0 && i < R) return run[i];
-        if constexpr (H <= R) {
-            if (i < 0) return lane > 0 ? run[i - (LY::RUN - R)] : nan;
-            return lane < 63 ? run[i + (LY::RUN - R)] : nan;
-        } else {
-            const int c = lane * R + i;
-            return (c >= 0 && c < 64 * R) ? myrow[LY::index(c)] : nan;
-        }
-    };
     dmax = -__builtin_inff();
     SortedWindow<WIDTH> win;
     win.reset();
@@ -318,6 +303,30 @@ __device__ __forceinline__ void median_phase(const float *myrow, int lane, float
             dev[j] = d;
         }
     }
+}
+
+template <int R, int WIDTH>
+__device__ __forceinline__ void median_phase(const float *myrow, int lane, float (&dev)[R],
+                                             float &dmax)
+{
+    using LY = FusedLayout<R>;
+    constexpr int H = WIDTH / 2;
+    const float *run = myrow + lane * LY::RUN;
+    const float nan = __builtin_nanf("");
+    // amplitude of channel lane*R + i, -H <= i < R + H. When the window reaches no
+    // further than the neighbouring lanes' runs, which sit RUN = R + 4 words away,
+    // every address is `run` plus a constant.
+    auto amp_rel = [&](int i) -> float {
+        if (i >= 0 && i < R) return run[i];
+        if constexpr (H <= R) {
+            if (i < 0) return lane > 0 ? run[i - (LY::RUN - R)] : nan;
+            return lane < 63 ? run[i + (LY::RUN - R)] : nan;
+        } else {
+            const int c = lane * R + i;
+            return (c >= 0 && c < 64 * R) ? myrow[LY::index(c)] : nan;
+        }
+    };
+    median_phase_src<R, WIDTH>(amp_rel, dev, dmax);
 }
 
 // Exact float64 deviation of channel c, recomputed from the amplitudes of its window

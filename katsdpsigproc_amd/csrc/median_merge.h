@@ -106,14 +106,25 @@ struct MergeMedian {
     __device__ __forceinline__ void run_lane(const float *run, int lane, float (&dev)[R],
                                              float &dmax)
     {
+        run_src([&](int i) { return run[i]; }, [&](int i) { return run[i - RUN_GAP]; },
+                [&](int i) { return run[i + RUN_GAP]; }, lane, dev, dmax);
+    }
+
+    // General form: in(i) is the lane's own sample i (0 <= i < R), left(i) (i < 0) and
+    // right(i) (i >= R) those of the neighbouring lanes -- asked for only where such a
+    // lane exists; beyond the band the +-inf stand-ins are supplied here.
+    template <class In, class Left, class Right>
+    __device__ __forceinline__ void run_src(In &&in, Left &&left, Right &&right, int lane,
+                                            float (&dev)[R], float &dmax)
+    {
         pinf = __builtin_inff();
         ninf = -__builtin_inff();
         asm volatile("" : "+v"(pinf), "+v"(ninf));
         // sample i of the lane, -H <= i < R + H
         auto xs = [&](int i) -> float {
-            if (i >= 0 && i < R) return run[i];
-            if (i < 0) return lane > 0 ? run[i - RUN_GAP] : (((-i) & 1) ? pinf : ninf);
-            return lane < 63 ? run[i + RUN_GAP] : (((i - R) & 1) ? ninf : pinf);
+            if (i >= 0 && i < R) return in(i);
+            if (i < 0) return lane > 0 ? left(i) : (((-i) & 1) ? pinf : ninf);
+            return lane < 63 ? right(i) : (((i - R) & 1) ? ninf : pinf);
         };
         dmax = ninf;
         constexpr int STAGES = (R + W - 1) / W;
