@@ -528,6 +528,14 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
 {
     constexpr int NP = R / 2;
     const int c0 = lane * R;
+    // dev[j] behind an opaque copy, for the rarely taken paths below: without it the
+    // compiler shares their |dev| patterns and keys with the key generation and keeps
+    // 128 values alive across the whole search for them
+    auto dv = [&](int j) -> float {
+        float x = dev[j];
+        asm("" : "+v"(x));
+        return x;
+    };
     // 1. 15-bit keys, two per register: the top 16 bits of |dev|'s float32 pattern,
     //    ROUNDED UP (key = (pattern + 0xffff) >> 16), so that key 0 means exactly zero
     //    and the zeros can be counted from the bit planes below instead of with a
@@ -630,7 +638,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     if (debug_stop == 32) return (double)(K + below_bin);
     // (keys are re-derived from the deviations from here on: kp may die)
     auto key_of = [&](int j) -> unsigned {
-        return min((__float_as_uint(dev[j]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu) >> 16;
+        return min((__float_as_uint(dv(j)) & 0x7fffffffu) + 0xffffu, 0x7fffffffu) >> 16;
     };
     auto bin_mask = [&](unsigned key) -> unsigned long long {
         unsigned long long m = 0;
@@ -654,7 +662,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             const unsigned test = first + (offs | (1u << bit));
             int c = 0;
 #pragma unroll
-            for (int j = 0; j < R; j++) c += (__float_as_uint(dev[j]) & 0x7fffffffu) < test;
+            for (int j = 0; j < R; j++) c += (__float_as_uint(dv(j)) & 0x7fffffffu) < test;
             c = ksp_wave_sum(c);
             if (c <= rank) {
                 offs |= 1u << bit;
@@ -665,7 +673,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         cand = 0;
 #pragma unroll
         for (int j = 0; j < R; j++)
-            if ((__float_as_uint(dev[j]) & 0x7fffffffu) == cur) cand |= 1ull << j;
+            if ((__float_as_uint(dv(j)) & 0x7fffffffu) == cur) cand |= 1ull << j;
         in_bin = ksp_wave_sum(__popcll(cand));
         r = rank - below;
         below_bin = below;
@@ -691,14 +699,14 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
                 float b32 = 0.0f;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    const float a = fabsf(dev[j]);
+                    const float a = fabsf(dv(j));
                     b32 = (__float_as_uint(a) < cur) ? fmaxf(b32, a) : b32;
                 }
                 b32 = ksp_wave_max(b32);
                 unsigned long long bm = 0;
 #pragma unroll
                 for (int j = 0; j < R; j++)
-                    if (fabsf(dev[j]) == b32) bm |= 1ull << j;
+                    if (fabsf(dv(j)) == b32) bm |= 1ull << j;
                 const int n2 = gather_exact<WIDTH>(bm, c0, list, 0, LIST_CAP, fetch);
                 double below_max = 0.0;
                 for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
@@ -777,12 +785,12 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         float b32 = 0.0f;
 #pragma unroll
         for (int j = 0; j < R; j++)
-            if ((bm >> j) & 1) b32 = fmaxf(b32, fabsf(dev[j]));
+            if ((bm >> j) & 1) b32 = fmaxf(b32, fabsf(dv(j)));
         b32 = ksp_wave_max(b32);
         unsigned long long top = 0;
 #pragma unroll
         for (int j = 0; j < R; j++)
-            if (((bm >> j) & 1) && fabsf(dev[j]) == b32) top |= 1ull << j;
+            if (((bm >> j) & 1) && fabsf(dv(j)) == b32) top |= 1ull << j;
         const int n2 = gather_exact<WIDTH>(top, c0, list, 0, LIST_CAP, fetch);
         double below_max = 0.0;
         for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
