@@ -195,7 +195,7 @@ class TestFused:
     @pytest.mark.parametrize(
         "channels, baselines",
         [(1, 1), (13, 8), (14, 3), (100, 17), (256, 8), (257, 9), (1000, 37), (1024, 64),
-         (1025, 5), (4096, 24), (4095, 11)],
+         (1025, 5), (4096, 24), (4095, 11), (4096, 9), (4096, 3), (2048, 13)],
     )  # fmt: skip
     @pytest.mark.parametrize("mode", ["none", "full"])
     def test_ragged_shapes(self, channels, baselines, mode, context, command_queue, oracle):
