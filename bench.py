@@ -5,12 +5,16 @@ One "step" = one pass of the full flagger (median-filter background, MAD noise
 estimate, SumThreshold) over one block of synthetic visibilities that is already
 resident in HBM: 4096 channels x 32768 baselines of complex64 per GPU
 (BASELINE.json config 4; with N GPUs the baselines are sharded, N x 32768 in total,
-config 5). Prints ONE JSON line (see the task contract): whole-job samples/s, the
-HBM roofline of the dominant kernel from HIP-event timing, and a CPU baseline (the
-oracle's C restatement of rfi.host, timed on this box's cores).
+config 5, and every step broadcasts the per-channel flag mask over RCCL). Prints ONE
+JSON line (see the task contract): whole-job samples/s, the HBM roofline of the step
+(zero-fill of the flags + the fused kernel) from HIP-event timing, the same workload
+with injected interference (``rfi_variant``), a check of the timed launch's output
+against the CPU oracle, the bring-up shapes of BASELINE.json configs 2 and 3, and a CPU
+baseline (the oracle's C restatement of rfi.host, timed on this box's cores).
 
     python bench.py                      # 1 GPU
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+    python bench.py --gpus N             # starts N ranks itself (torch.distributed.run)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   # the same
 
 Parameters follow scripts/rfiflagtest.py of the reference: width 13, 11 sigma,
 4 windows, falloff 1.2, RandomState(seed=1) standard-normal real/imag.
@@ -19,6 +23,8 @@ Parameters follow scripts/rfiflagtest.py of the reference: width 13, 11 sigma,
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +40,7 @@ WIDTH = 13
 N_SIGMA = 11.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ALGORITHMIC_BYTES_PER_SAMPLE = 9  # 8 B complex64 read + 1 B flag written
+CHECK_BASELINES = 512  # slice of the timed launch's output compared with the oracle
 
 
 def synth_block(channels: int, baselines: int, seed: int) -> np.ndarray:
@@ -48,6 +55,28 @@ def synth_block(channels: int, baselines: int, seed: int) -> np.ndarray:
     return out
 
 
+def inject_rfi(vis: np.ndarray, seed: int = 3, fraction: float = 1.0 / 16.0, block: int = 256):
+    """Interference as reference test/rfi/test_flagger.py:42-50 adds it (a random
+    `fraction` of the samples, amplitude U(50, 70), random phase), drawn for the hit
+    samples only and in blocks of rows so that 10^8 samples take seconds. In place."""
+    rs = np.random.RandomState(seed=seed)
+    for r0 in range(0, vis.shape[0], block):
+        part = vis[r0 : r0 + block]
+        hit = rs.random_sample(part.shape) < fraction
+        n = int(np.count_nonzero(hit))
+        amp = rs.random_sample(n) * 20.0 + 50.0
+        phase = rs.random_sample(n) * (2.0 * np.pi)
+        part[hit] += (amp * np.exp(1j * phase)).astype(np.complex64)
+    return vis
+
+
+def host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(budget_s: float = 20.0):
     """Time the oracle (C restatement of rfi.host.FlaggerHost) on one core.
 
@@ -56,11 +85,7 @@ def cpu_baseline(budget_s: float = 20.0):
     """
     from oracle import rfi_oracle as oracle
 
-    try:
-        cores_available = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores_available = os.cpu_count() or 1
-    threads = max(1, min(cores_available, oracle.max_threads(), 64))
+    threads = max(1, min(host_cores(), oracle.max_threads(), 64))
     oracle.set_threads(1)
     baselines = 512
     vis = synth_block(CHANNELS, baselines, 1)
@@ -92,6 +117,33 @@ def cpu_baseline(budget_s: float = 20.0):
         "all_cores_value": samples / dt_all,
         "all_cores": threads,
         "host_cpus": os.cpu_count(),
+    }
+
+
+def check_against_oracle(vis_slice, mask, flags_slice, noise_slice) -> dict:
+    """Compare a slice of a timed launch's output with the CPU oracle (outside the timed
+    region; the oracle is the checker, never the thing measured). Exits loudly on a
+    mismatch: a fast kernel with different results is not a result."""
+    from oracle import rfi_oracle as oracle
+
+    oracle.set_threads(max(1, min(host_cores(), oracle.max_threads(), 64)))
+    try:
+        ref_flags, ref_noise = oracle.flagger_full(vis_slice, mask, width=WIDTH, n_sigma=N_SIGMA)
+    finally:
+        oracle.set_threads(1)
+    flags_equal = bool(np.array_equal(ref_flags, flags_slice))
+    noise_equal = bool(np.array_equal(ref_noise.astype(np.float32), noise_slice, equal_nan=True))
+    if not (flags_equal and noise_equal):
+        raise SystemExit(
+            f"bench.py: GPU output differs from the oracle (flags_equal={flags_equal}, "
+            f"noise_equal={noise_equal}) on the first {vis_slice.shape[1]} baselines"
+        )
+    return {
+        "against": "oracle (C restatement of rfi.host.FlaggerHost)",
+        "slice": f"{vis_slice.shape[0]} ch x {vis_slice.shape[1]} bl of the timed block",
+        "flags_equal": flags_equal,
+        "noise_equal": noise_equal,
+        "flags_set_in_slice": int(np.count_nonzero(ref_flags)),
     }
 
 
@@ -130,7 +182,108 @@ class _StdoutToStderr:
         return False
 
 
-def main() -> None:
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child
+    `torch.distributed.run` and relay rank 0's JSON line. This process never touches
+    the GPU (nothing here imports torch or the HIP library)."""
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+        f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+        "--master-port", str(free_port()), os.path.abspath(__file__),
+    ] + argv  # fmt: skip
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for text in proc.stdout.splitlines():
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        elif text.strip():
+            print(text, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def time_op(queue, fn, reps: int = 20) -> float:
+    """Average device seconds per call of `fn` (HIP events on the queue's stream)."""
+    fn()
+    queue.finish()
+    a = queue.enqueue_marker()
+    for _ in range(reps):
+        fn()
+    b = queue.enqueue_marker()
+    queue.finish()
+    return b.time_since(a) / reps
+
+
+def bringup_configs(context, queue, vis_host) -> dict:
+    """BASELINE.json configs 2 and 3 (the bring-up shapes), one GPU, HIP-event timing,
+    algorithmic bytes of SURVEY.md 8(d). The 64-512 MiB arrays partly live in the
+    256 MiB Infinity Cache between repeats, so these are upper bounds for larger inputs."""
+    from katsdpsigproc_amd import percentile, transpose
+    from katsdpsigproc_amd.rfi import device
+
+    def entry(seconds, nbytes, note):
+        gbs = nbytes / seconds / 1e9
+        return {"ms": 1e3 * seconds, "algorithmic_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes": note}  # fmt: skip
+
+    out = {}
+    n = 4096
+    rs = np.random.RandomState(1)
+    src = np.abs(rs.standard_normal((n, n))).astype(np.float32)
+    op = transpose.TransposeTemplate(context, np.float32, "float").instantiate(queue, (n, n))
+    op.ensure_all_bound()
+    op.buffer("src").set(queue, src)
+    out["config2_transpose_4096x4096_f32"] = entry(time_op(queue, op), 8 * n * n, "8 B/element")
+    op = percentile.Percentile5Template(context, n, is_amplitude=True).instantiate(queue, (n, n))
+    op.ensure_all_bound()
+    op.buffer("src").set(queue, src)
+    out["config2_percentile5_4096x4096_f32"] = entry(time_op(queue, op), 4 * n * n, "4 B/element")
+    del op
+    C, B = 4096, 8192
+    block = np.ascontiguousarray(vis_host[:, :B])
+    bg = device.BackgroundMedianFilterDeviceTemplate(context, WIDTH).instantiate(queue, C, B)
+    bg.ensure_all_bound()
+    bg.buffer("vis").set(queue, block)
+    out["config3_background_4096x8192_c64"] = entry(time_op(queue, bg), 12 * C * B, "12 B/sample")
+    dev = bg.buffer("deviations").get(queue)
+    for name, tmpl in (
+        ("config3_noise_mad_4096x8192", device.NoiseEstMADDeviceTemplate(context)),
+        ("config3_noise_mad_t_4096x8192", device.NoiseEstMADTDeviceTemplate(context, 10240)),
+    ):
+        ne = tmpl.instantiate(queue, C, B)
+        ne.ensure_all_bound()
+        ne.buffer("deviations").set(queue, np.ascontiguousarray(dev.T) if tmpl.transposed else dev)
+        out[name] = entry(time_op(queue, ne), 4 * C * B, "4 B/sample")
+    del dev, bg, ne
+    # the reference-shaped five-kernel sequence and the fused kernel on config 3's block
+    for fused in (False, True):
+        template = device.FlaggerDeviceTemplate(
+            device.BackgroundMedianFilterDeviceTemplate(context, WIDTH),
+            device.NoiseEstMADTDeviceTemplate(context, 10240),
+            device.ThresholdSumDeviceTemplate(context),
+            fused=fused,
+        )
+        fn = template.instantiate(queue, C, B, threshold_args={"n_sigma": N_SIGMA})
+        fn.ensure_all_bound()
+        fn.buffer("vis").set(queue, block)
+        key = "flagger_fused_4096x8192" if fused else "flagger_sequence_5_kernels_4096x8192"
+        out[key] = entry(time_op(queue, fn), 9 * C * B, "9 B/sample")
+    return out
+
+
+def main() -> int:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=20)
@@ -139,18 +292,25 @@ def main() -> None:
                         help="baselines per GPU (default: the benchmark configuration)")  # fmt: skip
     parser.add_argument("--channels", type=int, default=CHANNELS)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-extras", action="store_true",
+                        help="skip the RFI-laden variant and the config 2/3 legs (N = 1 only)")  # fmt: skip
     parser.add_argument("--keep-deviations", action="store_true",
                         help="also write the deviations slot (13 B/sample variant)")  # fmt: skip
     parser.add_argument("--sequence", action="store_true",
                         help="time the reference-shaped 5-kernel sequence instead of the fused kernel")  # fmt: skip
     args = parser.parse_args()
 
+    # KSP_BENCH_FORCE_LAUNCH=1 takes the launcher route for N = 1 too (rehearsal of the
+    # self-launch on a one-GPU box, together with KSP_BENCH_FORCE_DIST=1)
+    if "WORLD_SIZE" not in os.environ and (
+        args.gpus > 1 or os.environ.get("KSP_BENCH_FORCE_LAUNCH") == "1"
+    ):
+        return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     torch = None
     # KSP_BENCH_FORCE_DIST=1 exercises the torch.distributed code path with a single
@@ -197,7 +357,8 @@ def main() -> None:
     # synthetic input, resident in HBM before the timed region
     vis = synth_block(channels, baselines, seed=1 + rank)
     fn.buffer("vis").set(queue, vis)
-    del vis
+    n_check = min(CHECK_BASELINES, baselines)
+    mask = None
     pipe = None
     if use_dist:
         # The channel mask is rank 0's to decide and changes from block to block in a
@@ -252,43 +413,66 @@ def main() -> None:
         if torch is not None:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
+    def timed(steps: int, warmup: int, barrier: bool):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronise.
+        Returns (wall seconds, per-step device seconds, per-launch kernel seconds): HIP
+        events on the flagger's stream around every step (zero-fill + kernel) and, for
+        the fused path, around the kernel itself."""
+        for _ in range(warmup):
+            step()
+        sync()
+        if barrier and dist is not None:
+            dist.barrier()
+        sync()
+        marks = [queue.enqueue_marker()]
+        kernel_events = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if not args.sequence:
+                kernel_events.append(fn.profile_next_run())
+            step()
+            marks.append(queue.enqueue_marker())
+        sync()
+        if barrier and dist is not None:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        step_s = [b.time_since(a) for a, b in zip(marks[:-1], marks[1:])]
+        kernel_s = [stop.time_since(start) for start, stop in kernel_events]
+        return wall, step_s, kernel_s
+
+    elapsed, step_s, kernel_s = timed(args.steps, args.warmup, True)
+    if not kernel_s:
+        kernel_s = step_s
+    stats = [elapsed, float(np.mean(step_s)), float(np.mean(kernel_s)),
+             float(np.max(step_s)), float(np.max(kernel_s)),
+             -float(np.min(step_s)), -float(np.min(kernel_s))]  # fmt: skip
     if dist is not None:
-        dist.barrier()
-    sync()
-    start_evt = queue.enqueue_marker()
-    kernel_events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if not args.sequence:
-            # HIP events recorded around the flagger kernel itself, on its stream
-            kernel_events.append(fn.profile_next_run())
-        step()
-    end_evt = queue.enqueue_marker()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    device_s = end_evt.time_since(start_evt)
-    if kernel_events:
-        device_s = sum(stop.time_since(start) for start, stop in kernel_events)
-    if dist is not None:
-        t = torch.tensor([elapsed, device_s], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor(stats, dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, device_s = float(t[0]), float(t[1])
+        stats = [float(x) for x in t]
+    elapsed, step_mean, kernel_mean, step_max, kernel_max, step_min, kernel_min = stats
+    step_min, kernel_min = -step_min, -kernel_min
 
-    samples_per_step = channels * baselines * world
-    value = samples_per_step * args.steps / elapsed
-    # dominant kernel: flagger_fused_kernel; its average launch duration comes from the
-    # HIP events armed around every launch (the zero-fill of the flags, a separate
-    # memset kernel of ~19 us, is part of the step but not of this kernel)
-    kernel_s = device_s / args.steps
+    # the timed launch's own output against the oracle (every rank checks its block)
+    verified = None
+    if not args.sequence:
+        flags_out = fn.buffer("flags").get(queue)
+        noise_out = fn.buffer("noise").get(queue)
+        verified = check_against_oracle(
+            np.ascontiguousarray(vis[:, :n_check]), mask,
+            flags_out[:, :n_check], noise_out[:n_check],
+        )  # fmt: skip
+        verified["flagged_fraction_of_block"] = float(np.count_nonzero(flags_out)) / flags_out.size
+        del flags_out
+
+    samples_per_gpu = channels * baselines
     n_bytes = ALGORITHMIC_BYTES_PER_SAMPLE + (4 if args.keep_deviations else 0)
-    achieved = channels * baselines * n_bytes / kernel_s / 1e9
+    value = samples_per_gpu * world * args.steps / elapsed
 
+    result = None
     if rank == 0:
+        achieved = samples_per_gpu * world * n_bytes / step_mean / 1e9
+        peak = HBM_PEAK_GBS * world
         result = {
             "metric": "visibility samples/s (baselines x channels) through full RFI flagger",
             "value": value,
@@ -310,26 +494,63 @@ def main() -> None:
                 "use_flags": use_flags.name,
                 "keep_deviations": bool(args.keep_deviations),
                 "sharding": f"baselines over {world} GPU(s)"
-                            + (", RCCL broadcast of the channel mask per step" if use_dist else ""),
+                            + (", RCCL broadcast of the channel mask per step; N > 1 runs"
+                               " BackgroundFlags.CHANNEL (1/16 of the channels masked), N = 1"
+                               " runs without input flags" if use_dist else ""),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "sequence" if args.sequence else "flagger_fused_kernel",
+                "kernel": "sequence" if args.sequence
+                          else "flagger_fused_kernel + zero-fill of flags (one step)",
                 "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
+                "peak": peak,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / peak,
                 "algorithmic_bytes_per_sample": n_bytes,
-                "kernel_ms": 1e3 * kernel_s,
+                "step_device_ms": {"mean": 1e3 * step_mean, "min": 1e3 * step_min,
+                                   "max": 1e3 * step_max},
+                "kernel_ms": {"mean": 1e3 * kernel_mean, "min": 1e3 * kernel_min,
+                              "max": 1e3 * kernel_max},
+                "frac_kernel_only": samples_per_gpu * n_bytes / kernel_mean / 1e9 / HBM_PEAK_GBS,
                 "traffic": measured_traffic(channels, baselines, use_flags.name, args),
             },
+            "verified": verified,
+        }  # fmt: skip
+
+    extras = world == 1 and not use_dist and not args.no_extras and not args.sequence
+    if extras:
+        # the same launch on RFI-laden input: SumThreshold's windows are summed and the
+        # flagged bytes written (the plain input of the reference's script gives 0 flags)
+        inject_rfi(vis, seed=3)
+        fn.buffer("vis").set(queue, vis)
+        r_elapsed, r_step, r_kernel = timed(args.steps, 2, False)
+        flags_out = fn.buffer("flags").get(queue)
+        noise_out = fn.buffer("noise").get(queue)
+        r_verified = check_against_oracle(
+            np.ascontiguousarray(vis[:, :n_check]), None,
+            flags_out[:, :n_check], noise_out[:n_check],
+        )  # fmt: skip
+        result["rfi_variant"] = {
+            "input": "the same block + interference on 1/16 of the samples (amplitude U(50,70))",
+            "ms_per_step": 1e3 * r_elapsed / args.steps,
+            "step_device_ms": 1e3 * float(np.mean(r_step)),
+            "kernel_ms": 1e3 * float(np.mean(r_kernel)),
+            "frac": samples_per_gpu * n_bytes / float(np.mean(r_step)) / 1e9 / HBM_PEAK_GBS,
+            "flagged_fraction": float(np.count_nonzero(flags_out)) / flags_out.size,
+            "verified": r_verified,
         }
+        del flags_out
+        result["bringup"] = bringup_configs(context, queue, vis)
+    del vis
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -188,6 +188,22 @@ int ksp_selftest_sqrt12(int device, void *stream, float *out, int n);
 int ksp_selftest_abs(int device, void *stream, const float *re, const float *im, float *out,
                      int n);
 
+/* Self-tests of the rank / reduction library (csrc/rank.h, bitplane.h), the counterpart
+ * of the reference's test kernels test/test_rank.mako:37-113 driven by
+ * test/test_rank.py:67-213. One 256-thread workgroup each; device pointers.
+ * ksp_selftest_rank: out[q] = number of the n <= 2048 non-negative floats in data that
+ *   are strictly below q, for 0 <= q < m (rank.mako:31-105 `rank`; NaN never counts).
+ * ksp_selftest_minmax: out[0] / out[1] = smallest / largest non-NaN value of the
+ *   n <= 2048 floats, NaN if all are NaN (rank.mako:57-84).
+ * ksp_selftest_median_non_zero: median of the non-zero values of n <= 16384
+ *   non-negative floats (float32 mean of the middle two for an even count,
+ *   rank.mako:253-267): out[0] by the workgroup search, out[1] by the wavefront
+ *   bit-plane search when n <= 4096 (else the workgroup search again). */
+int ksp_selftest_rank(int device, void *stream, const float *data, int *out, int n, int m);
+int ksp_selftest_minmax(int device, void *stream, const float *data, float *out, int n);
+int ksp_selftest_median_non_zero(int device, void *stream, const float *data, float *out,
+                                 int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,9 @@ SIGNATURES = {
     "ksp_flagger_fused_profile": [c_void_p, c_void_p],
     "ksp_selftest_sqrt12": [c_int, c_void_p, c_void_p, c_int],
     "ksp_selftest_abs": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "ksp_selftest_rank": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int],
+    "ksp_selftest_minmax": [c_int, c_void_p, c_void_p, c_void_p, c_int],
+    "ksp_selftest_median_non_zero": [c_int, c_void_p, c_void_p, c_void_p, c_int],
     "ksp_background_median_filter": [
         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
         c_int,

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     const int b0 = strip_of(blockIdx.x, p.n_strips) * FUSED_STRIP;
 
     // diagnostic time stamps (shader clock) of this wavefront's phases
-    unsigned long long *trace = p.trace ? p.trace + ((size_t)blockIdx.x * FUSED_STRIP + wave) * 16 : nullptr;
+    unsigned long long *trace = FUSED_DIAG_TRACE(p) ? FUSED_DIAG_TRACE(p) + ((size_t)blockIdx.x * FUSED_STRIP + wave) * 16 : nullptr;
     auto stamp = [&](int i) {
         if (trace != nullptr && lane == 0) trace[i] = __builtin_amdgcn_s_memtime();
     };
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     stamp(1);
     const bool any_masked = __syncthreads_or(masked);
     stamp(2);
-    if (p.debug_stop == 1 || p.debug_stop == 11) return;
+    if (FUSED_DIAG_STOP(p) == 1 || FUSED_DIAG_STOP(p) == 11) return;
 
     const int bl = b0 + wave;
     float *myrow = lds + wave * LY::ROW;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     bool merged = false;
     if constexpr (R == 64) {
         // clean strip over the whole band: the merging median (median_merge.h)
-        if (!any_masked && C == 64 * R && p.debug_stop != 21) {
+        if (!any_masked && C == 64 * R && FUSED_DIAG_STOP(p) != 21) {
             MergeMedian<R, WIDTH> mm;
             mm.template run_lane<LY::RUN - R>(myrow + lane * LY::RUN, lane, dev, dmax);
             merged = true;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     if (!merged) median_phase<R, WIDTH>(myrow, lane, dev, dmax);
     stamp(3);
     const FusedParams &pa = p;
-    if (pa.debug_stop == 2) {
+    if (FUSED_DIAG_STOP(pa) == 2) {
         float acc = dmax;
 #pragma unroll
         for (int j = 0; j < R; j++) acc += dev[j];
@@ -99,15 +99,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         return;
     }
 
-    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, pa.debug_stop, trace);
+    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, FUSED_DIAG_STOP(pa), trace);
     if (lane == 0 && pa.noise != nullptr && bl < pa.baselines) pa.noise[bl] = (float)noise64;
     stamp(4);
-    if (pa.debug_stop == 3 || pa.debug_stop > 30) return;
+    if (FUSED_DIAG_STOP(pa) == 3 || FUSED_DIAG_STOP(pa) > 30) return;
 
     const unsigned long long fl =
         threshold_flags<R, WIDTH>(pa, dev, dmax, noise64, lane, C, fetch);
     stamp(5);
-    if (pa.debug_stop == 4) {
+    if (FUSED_DIAG_STOP(pa) == 4) {
         if (fl == 0x123456789abcull && pa.noise) pa.noise[0] = 1.0f;
         return;
     }
@@ -155,42 +155,48 @@ static int launch_fused(int device, hipStream_t s, const FusedParams &p)
         KSP_CHECK(hipFuncSetAttribute((const void *)kern,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         if (device >= 0 && device < 64) attr_set[device].store(true, std::memory_order_release);
+#ifdef KSP_DIAG
         if (getenv("KSP_FUSED_DEBUG_OCC")) {
             int nb = -1;
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FUSED_THREADS, lds_bytes);
             fprintf(stderr, "flagger_fused_kernel<%d>: %d workgroups/CU, LDS %zu B\n", R, nb, lds_bytes);
         }
+#endif
     }
+#ifdef KSP_DIAG
     const char *trace_path = getenv("KSP_FUSED_DEBUG_TRACE");
-    if (trace_path == nullptr) {
-        if (g_prof_start != nullptr) {
-            // time exactly this kernel (not the zero-fill before it)
-            hipExtLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s,
-                                  g_prof_start, g_prof_stop, 0, p);
-            g_prof_start = g_prof_stop = nullptr;
-        } else {
-            hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
-        }
+    if (trace_path != nullptr) {
+        // diagnostic run: collect per-wavefront phase time stamps and dump them
+        g_prof_start = g_prof_stop = nullptr;
+        FusedParams pt = p;
+        const size_t n = (size_t)p.n_strips * FUSED_STRIP * 16;
+        KSP_CHECK(hipMalloc(&pt.trace, n * 8));
+        KSP_CHECK(hipMemsetAsync(pt.trace, 0, n * 8, s));
+        hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, pt);
         KSP_LAUNCH_CHECK();
+        KSP_CHECK(hipStreamSynchronize(s));
+        unsigned long long *host = (unsigned long long *)malloc(n * 8);
+        KSP_CHECK(hipMemcpy(host, pt.trace, n * 8, hipMemcpyDeviceToHost));
+        KSP_CHECK(hipFree(pt.trace));
+        FILE *f = fopen(trace_path, "wb");
+        if (f != nullptr) {
+            fwrite(host, 8, n, f);
+            fclose(f);
+        }
+        free(host);
         return 0;
     }
-    // diagnostic run: collect per-wavefront phase time stamps and dump them
-    FusedParams pt = p;
-    const size_t n = (size_t)p.n_strips * FUSED_STRIP * 16;
-    KSP_CHECK(hipMalloc(&pt.trace, n * 8));
-    KSP_CHECK(hipMemsetAsync(pt.trace, 0, n * 8, s));
-    hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, pt);
+#endif
+    // events armed by ksp_flagger_fused_profile time exactly this kernel (not the
+    // zero-fill before it); they are consumed by this launch whatever its outcome
+    const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
+    if (ev0 != nullptr)
+        hipExtLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, ev0, ev1,
+                              0, p);
+    else
+        hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
     KSP_LAUNCH_CHECK();
-    KSP_CHECK(hipStreamSynchronize(s));
-    unsigned long long *host = (unsigned long long *)malloc(n * 8);
-    KSP_CHECK(hipMemcpy(host, pt.trace, n * 8, hipMemcpyDeviceToHost));
-    KSP_CHECK(hipFree(pt.trace));
-    FILE *f = fopen(trace_path, "wb");
-    if (f != nullptr) {
-        fwrite(host, 8, n, f);
-        fclose(f);
-    }
-    free(host);
     return 0;
 }
 
@@ -255,11 +261,13 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     p.n_windows = n_windows;
     p.flag_value = flag_value;
     p.n_strips = ksp_divup(baselines, FUSED_STRIP);
+#ifdef KSP_DIAG
     p.trace = nullptr;
     {
         const char *dbg = getenv("KSP_FUSED_DEBUG_STOP");
         p.debug_stop = dbg ? atoi(dbg) : 0;
     }
+#endif
     p.n_sigma = n_sigma;
     for (int k = 0; k < KSP_MAX_WINDOWS; k++)
         p.scales[k] = (scales64 != nullptr && k < n_windows) ? scales64[k] : 0.0;

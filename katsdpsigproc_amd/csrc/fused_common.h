@@ -14,6 +14,17 @@
 #define FUSED_THREADS (64 * FUSED_STRIP)
 #define FUSED_MAD_NORMAL 1.4826
 
+// Diagnostics (phase probes, per-wavefront time stamps) exist only in builds made with
+// KSP_EXTRA_HIPCC_FLAGS=-DKSP_DIAG (tools/phase_probe.py, tools/trace_phases.py); in the
+// product build these fold to constants and the code behind them disappears.
+#ifdef KSP_DIAG
+#define FUSED_DIAG_STOP(p) ((p).debug_stop)
+#define FUSED_DIAG_TRACE(p) ((p).trace)
+#else
+#define FUSED_DIAG_STOP(p) 0
+#define FUSED_DIAG_TRACE(p) ((unsigned long long *)nullptr)
+#endif
+
 struct FusedParams {
     const void *vis;
     const uint8_t *in_flags;
@@ -24,8 +35,10 @@ struct FusedParams {
     int vis_stride, in_flags_stride, flags_stride, dev_stride;
     int is_amplitude, flags_mode, threshold_kind, n_windows, flag_value;
     int n_strips;
-    int debug_stop;  // diagnostic only (env KSP_FUSED_DEBUG_STOP): 0 = run everything
-    unsigned long long *trace;  // diagnostic only (env KSP_FUSED_DEBUG_TRACE): phase time stamps
+#ifdef KSP_DIAG
+    int debug_stop;  // diagnostic builds only (env KSP_FUSED_DEBUG_STOP): 0 = run everything
+    unsigned long long *trace;  // diagnostic builds only (env KSP_FUSED_DEBUG_TRACE): phase time stamps
+#endif
     double n_sigma;
     double scales[KSP_MAX_WINDOWS];
 };
@@ -213,7 +226,7 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
         for (int u = 0; u < LB; u++) {
             const int row = rbase + r0 + u * RSTEP;
             float a0, a1;
-            if (p.debug_stop == 11) {  // diagnostic: how long does the loader take without arithmetic?
+            if (FUSED_DIAG_STOP(p) == 11) {  // diagnostic: how long does the loader take without arithmetic?
                 a0 = raw[u].x;
                 a1 = raw[u].z;
             } else {
@@ -678,22 +691,55 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         r = rank - below;
         below_bin = below;
         if (in_bin > LIST_CAP) {
-            // still too many: they share one float32 value. If their exact values are
-            // all equal (the usual reason), that value is the answer for rank r and
-            // r - 1 alike; otherwise give the float32 value (documented limitation).
+            // Still too many: they share ONE float32 value, so their exact float64
+            // values all lie within half a float32 ulp of it. Select among them
+            // exactly by bisection on the float64 bit patterns (positive doubles order
+            // like their patterns; the span is at most ~2^29 patterns), recomputing the
+            // exact values on every pass -- a path only heavily quantised data takes.
+            auto each = [&](auto &&f) {
+                unsigned long long todo = cand;
+                while (__any(todo != 0)) {
+                    const bool has = todo != 0;
+                    const int j = has ? __ffsll((long long)todo) - 1 : 0;
+                    todo &= todo - 1;
+                    const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
+                    if (has) f(x);
+                }
+            };
             double lo = __builtin_inf(), hi = 0.0;
-            unsigned long long todo = cand;
-            while (__any(todo != 0)) {
-                const bool has = todo != 0;
-                const int j = has ? __ffsll((long long)todo) - 1 : 0;
-                todo &= todo - 1;
-                const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
-                lo = has ? fmin(lo, x) : lo;
-                hi = has ? fmax(hi, x) : hi;
-            }
+            each([&](double x) {
+                lo = fmin(lo, x);
+                hi = fmax(hi, x);
+            });
             lo = ksp_wave_min(lo);
             hi = ksp_wave_max(hi);
-            double xk = (lo == hi) ? lo : (double)__uint_as_float(cur);
+            double xk = lo, prev = lo;
+            if (lo != hi) {
+                const unsigned long long base = (unsigned long long)__double_as_longlong(lo);
+                const unsigned long long span = (unsigned long long)__double_as_longlong(hi) - base;
+                unsigned long long offs = 0;
+                int below_k = 0;
+                for (int bit = 63 - __clzll((long long)span); bit >= 0; bit--) {
+                    const unsigned long long test = base + (offs | (1ull << bit));
+                    int c = 0;
+                    each([&](double x) {
+                        c += (unsigned long long)__double_as_longlong(x) < test;
+                    });
+                    c = ksp_wave_sum(c);
+                    if (c <= r) {
+                        offs |= 1ull << bit;
+                        below_k = c;
+                    }
+                }
+                xk = __longlong_as_double((long long)(base + offs));
+                prev = xk;  // rank r - 1 is a duplicate of rank r ...
+                if (even && r >= 1 && below_k == r) {
+                    // ... unless exactly r values lie below: then it is the largest of them
+                    double m = 0.0;
+                    each([&](double x) { m = (x < xk) ? fmax(m, x) : m; });
+                    prev = ksp_wave_max(m);
+                }
+            }
             if (even && r == 0) {
                 // lower median lies below this value: largest float32 value below it
                 float b32 = 0.0f;
@@ -712,8 +758,23 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
                 for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
                 below_max = ksp_wave_max(below_max);
                 __builtin_amdgcn_wave_barrier();
-                xk = (xk + below_max) / 2.0;
+                // (more than LIST_CAP samples there too: they share the float32 value
+                // b32 and the largest exact one is wanted)
+                if (n2 > LIST_CAP) {
+                    unsigned long long todo = bm;
+                    double m = 0.0;
+                    while (__any(todo != 0)) {
+                        const bool has = todo != 0;
+                        const int j = has ? __ffsll((long long)todo) - 1 : 0;
+                        todo &= todo - 1;
+                        const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
+                        m = has ? fmax(m, x) : m;
+                    }
+                    below_max = ksp_wave_max(m);
+                }
+                prev = below_max;
             }
+            if (even) xk = (xk + prev) / 2.0;
             return xk * FUSED_MAD_NORMAL;
         }
     }
@@ -796,6 +857,18 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
         prev = ksp_wave_max(below_max);
         __builtin_amdgcn_wave_barrier();
+        if (n2 > LIST_CAP) {
+            // more ties at b32 than the list holds: largest exact value, no list
+            double m = 0.0;
+            while (__any(top != 0)) {
+                const bool has = top != 0;
+                const int j = has ? __ffsll((long long)top) - 1 : 0;
+                top &= top - 1;
+                const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
+                m = has ? fmax(m, x) : m;
+            }
+            prev = ksp_wave_max(m);
+        }
     }
     if (even) xk = (xk + prev) / 2.0;  // float64 mean, as numpy.median
     return xk * FUSED_MAD_NORMAL;

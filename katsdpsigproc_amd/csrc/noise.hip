@@ -30,23 +30,12 @@ __global__ __launch_bounds__(KSP_RANK_THREADS) void madnz_t_kernel(const float *
     const int t = threadIdx.x;
     const float *row = in + (size_t)bl * stride;
     float v[VT];
-    int zeros = 0;
 #pragma unroll
     for (int i = 0; i < VT; i++) {
         const int c = i * KSP_RANK_THREADS + t;
-        float a = __builtin_nanf("");
-        if (c < channels) {
-            a = fabsf(row[c]);
-            zeros += (a == 0.0f);
-        }
-        v[i] = a;
+        v[i] = (c < channels) ? fabsf(row[c]) : __builtin_nanf("");
     }
-    zeros = block_sum(zeros, &scratch);
-    // zeros sort first, so the median of the non-zero values has rank
-    // (channels + zeros) / 2 in the whole row (reference rank.mako:261-266)
-    const int rank2 = channels + zeros;
-    float med = block_select(v, rank2 / 2, !(rank2 & 1), &scratch);
-    if (zeros == channels) med = __builtin_nanf("");  // numpy: median of nothing
+    const float med = block_median_non_zero(v, channels, &scratch);
     if (t == 0) noise[bl] = (float)((double)med * KSP_MAD_NORMAL);
 }
 
@@ -128,6 +117,54 @@ __device__ __forceinline__ float wave_median_nonzero(const unsigned (&u)[64], in
     }
     if (zeros == channels) result = __builtin_nanf("");  // numpy: median of nothing
     return result;
+}
+
+// Self-test of the rank library (tests/test_gpu_ops.py::TestRankLibrary, the
+// counterpart of reference test/test_rank.py:161-213): median of the non-zero values of
+// `n` <= 16384 non-negative floats by the workgroup search (out[0]) and, for n <= 4096,
+// by the wavefront bit-plane search (out[1]; else the workgroup search again).
+template <int VT>
+__global__ __launch_bounds__(KSP_RANK_THREADS) void selftest_median_non_zero_kernel(
+    const float *__restrict__ data, int n, float *__restrict__ out)
+{
+    __shared__ RankScratch scratch;
+    const int t = threadIdx.x;
+    float v[VT];
+#pragma unroll
+    for (int i = 0; i < VT; i++) {
+        const int c = i * KSP_RANK_THREADS + t;
+        v[i] = (c < n) ? data[c] : __builtin_nanf("");
+    }
+    const float med = block_median_non_zero(v, n, &scratch);
+    if (t == 0) out[0] = out[1] = med;
+    if (n <= 4096 && t < 64) {
+        unsigned u[64];
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            u[i] = (t * 64 + i < n) ? (__float_as_uint(data[t * 64 + i]) & 0x7fffffffu) : 0x7fffffffu;
+        const float w = wave_median_nonzero(u, n);
+        if (t == 0) out[1] = w;
+    }
+}
+
+extern "C" int ksp_selftest_median_non_zero(int device, void *stream, const float *data,
+                                            float *out, int n)
+{
+    KSP_REQUIRE(data != nullptr && out != nullptr && n >= 1 && n <= 64 * KSP_RANK_THREADS,
+                "bad arguments");
+    KSP_CHECK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 4 * KSP_RANK_THREADS)
+        hipLaunchKernelGGL(selftest_median_non_zero_kernel<4>, dim3(1), dim3(KSP_RANK_THREADS), 0,
+                           s, data, n, out);
+    else if (n <= 40 * KSP_RANK_THREADS)
+        hipLaunchKernelGGL(selftest_median_non_zero_kernel<40>, dim3(1), dim3(KSP_RANK_THREADS), 0,
+                           s, data, n, out);
+    else
+        hipLaunchKernelGGL(selftest_median_non_zero_kernel<64>, dim3(1), dim3(KSP_RANK_THREADS), 0,
+                           s, data, n, out);
+    KSP_LAUNCH_CHECK();
+    return 0;
 }
 
 __global__ __launch_bounds__(256) void madnz_t_wave_kernel(const float *__restrict__ in,

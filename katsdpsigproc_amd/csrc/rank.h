@@ -155,3 +155,21 @@ __device__ __forceinline__ float block_select(const float (&v)[VT], int rank, bo
     }
     return result;
 }
+
+// Median of the non-zero values of a row of `n` non-negative floats held VT per thread
+// (NaN beyond the data), float32 mean of the middle two for an even count, NaN when
+// every value is zero (reference rank.mako:253-267: zeros are counted and the target
+// rank shifted past them instead of removing them).
+template <int VT>
+__device__ __forceinline__ float block_median_non_zero(const float (&v)[VT], int n, RankScratch *s)
+{
+    int zeros = 0;
+#pragma unroll
+    for (int i = 0; i < VT; i++) zeros += (v[i] == 0.0f);
+    zeros = block_sum(zeros, s);
+    // zeros sort first, so the median of the non-zero values has rank (n + zeros) / 2
+    const int rank2 = n + zeros;
+    float med = block_select(v, rank2 / 2, !(rank2 & 1), s);
+    if (zeros == n) med = __builtin_nanf("");  // numpy: median of nothing
+    return med;
+}

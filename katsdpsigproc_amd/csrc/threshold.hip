@@ -63,20 +63,25 @@ extern "C" int ksp_threshold_simple(int device, void *stream, const float *devia
 {
     KSP_REQUIRE(deviations != nullptr && noise != nullptr && flags != nullptr, "NULL buffer");
     KSP_REQUIRE(rows >= 0 && cols >= 0 && stride >= cols, "bad shape");
-    KSP_REQUIRE(rows <= 65535 * 1, "more than 65535 rows");
     if (rows == 0 || cols == 0) return 0;
     KSP_CHECK(hipSetDevice(device));
     const int vec_ok = (stride % 4 == 0) && ((uintptr_t)deviations % 16 == 0) &&
                        ((uintptr_t)flags % 4 == 0);
-    dim3 grid(ksp_divup(cols, 1024), rows);
-    if (transposed)
-        hipLaunchKernelGGL(threshold_simple_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
-                           deviations, noise, flags, rows, cols, stride, n_sigma,
-                           (uint8_t)flag_value, vec_ok);
-    else
-        hipLaunchKernelGGL(threshold_simple_kernel<false>, grid, dim3(256), 0,
-                           (hipStream_t)stream, deviations, noise, flags, rows, cols, stride,
-                           n_sigma, (uint8_t)flag_value, vec_ok);
+    // grid.y holds at most 65535 rows: larger arrays go in slices
+    for (int r0 = 0; r0 < rows; r0 += 65535) {
+        const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid(ksp_divup(cols, 1024), nr);
+        const float *d = deviations + (size_t)r0 * stride;
+        uint8_t *f = flags + (size_t)r0 * stride;
+        if (transposed)
+            hipLaunchKernelGGL(threshold_simple_kernel<true>, grid, dim3(256), 0,
+                               (hipStream_t)stream, d, noise + r0, f, nr, cols, stride, n_sigma,
+                               (uint8_t)flag_value, vec_ok);
+        else
+            hipLaunchKernelGGL(threshold_simple_kernel<false>, grid, dim3(256), 0,
+                               (hipStream_t)stream, d, noise, f, nr, cols, stride, n_sigma,
+                               (uint8_t)flag_value, vec_ok);
+    }
     KSP_LAUNCH_CHECK();
     return 0;
 }
@@ -93,10 +98,11 @@ __global__ __launch_bounds__(256) void threshold_sum_kernel(
     int core, int edge)
 {
     constexpr int TOT = 256 * VT;
-    constexpr int MAXW = 8;  // largest window (n_windows <= 4)
+    constexpr int MAXW = 1 << (KSP_MAX_WINDOWS - 1);  // largest window
     static_assert(VT >= 8 && VT < 57, "neighbour exchange assumes 8 <= VT < 57");
     __shared__ float vals[TOT + MAXW];
     __shared__ unsigned long long hitmask[256];
+    __shared__ int lasthit[256];
     __shared__ uint8_t fbytes[TOT];
 
     const int t = threadIdx.x;
@@ -163,18 +169,34 @@ __global__ __launch_bounds__(256) void threshold_sum_kernel(
             const bool valid = (g >= 0) && (g + w <= channels) && (j0 + i + w <= TOT);
             if (valid && s > limit) hits |= 1ull << i;
         }
-        // 3. dilate: a hit at j flags j .. j+w-1, possibly into the next thread
-        hitmask[t] = hits;
-        __syncthreads();
-        const unsigned long long prev = t > 0 ? hitmask[t - 1] : 0ull;
-        // bits 0..6 = previous thread's last 7 positions (VT >= 8 > w - 1),
-        // bits 7.. = own positions
-        unsigned long long comb = (hits << 7) | ((prev >> (VT - 7)) & 0x7full);
-        if (w >= 2) comb |= comb << 1;
-        if (w >= 4) comb |= comb << 2;
-        if (w >= 8) comb |= comb << 4;
-        fl |= (comb >> 7) & ((1ull << VT) - 1);
-        // hitmask is rewritten only after the next window's first barrier
+        // 3. dilate: a hit at j flags j .. j+w-1, possibly into the next thread(s)
+        if (w <= 8) {
+            hitmask[t] = hits;
+            __syncthreads();
+            const unsigned long long prev = t > 0 ? hitmask[t - 1] : 0ull;
+            // bits 0..6 = previous thread's last 7 positions (VT >= 8 > w - 1),
+            // bits 7.. = own positions
+            unsigned long long comb = (hits << 7) | ((prev >> (VT - 7)) & 0x7full);
+            if (w >= 2) comb |= comb << 1;
+            if (w >= 4) comb |= comb << 2;
+            if (w >= 8) comb |= comb << 4;
+            fl |= (comb >> 7) & ((1ull << VT) - 1);
+        } else {
+            // wide windows reach back over several threads: a position is flagged when
+            // the nearest hit at or before it is fewer than w positions away
+            constexpr int NONE = -(1 << 30);
+            lasthit[t] = hits ? j0 + 63 - __clzll((long long)hits) : NONE;
+            __syncthreads();
+            int carry = NONE;
+            const int reach = (w - 1 + VT - 1) / VT;
+            for (int q = 1; q <= reach && q <= t; q++) carry = max(carry, lasthit[t - q]);
+#pragma unroll
+            for (int i = 0; i < VT; i++) {
+                if ((hits >> i) & 1) carry = j0 + i;
+                if (j0 + i - carry < w) fl |= 1ull << i;
+            }
+        }
+        // hitmask / lasthit are rewritten only after the next window's first barrier
     }
     __syncthreads();
 #pragma unroll
@@ -196,8 +218,8 @@ extern "C" int ksp_threshold_sum(int device, void *stream, const float *deviatio
     KSP_REQUIRE(deviations != nullptr && noise != nullptr && flags != nullptr, "NULL buffer");
     KSP_REQUIRE(scales != nullptr, "scales is NULL");
     KSP_REQUIRE(channels >= 0 && baselines >= 0 && stride >= channels, "bad shape");
-    KSP_REQUIRE(n_windows >= 1 && n_windows <= 4, "n_windows must be 1..4 (windows up to 8)");
-    KSP_REQUIRE(baselines <= 65535, "more than 65535 baselines per launch");
+    KSP_REQUIRE(n_windows >= 1 && n_windows <= KSP_MAX_WINDOWS,
+                "n_windows must be 1..8 (windows up to 128)");
     if (channels == 0 || baselines == 0) return 0;
     KSP_CHECK(hipSetDevice(device));
     SumParams p;
@@ -210,9 +232,14 @@ extern "C" int ksp_threshold_sum(int device, void *stream, const float *deviatio
         const int core = (channels <= tot) ? tot : tot - 2 * edge;                        \
         const int chunks = ksp_divup(channels, core);                                            \
         const int e = (chunks == 1) ? 0 : edge;                                                  \
-        hipLaunchKernelGGL(threshold_sum_kernel<VT>, dim3(chunks, baselines), dim3(256), 0, s,  \
-                           deviations, noise, flags, channels, stride, n_sigma, p, n_windows,    \
-                           (uint8_t)flag_value, core, e);                                        \
+        /* grid.y holds at most 65535 baselines: larger arrays go in slices */                  \
+        for (int b0 = 0; b0 < baselines; b0 += 65535) {                                          \
+            const int nb = baselines - b0 < 65535 ? baselines - b0 : 65535;                      \
+            hipLaunchKernelGGL(threshold_sum_kernel<VT>, dim3(chunks, nb), dim3(256), 0, s,      \
+                               deviations + (size_t)b0 * stride, noise + b0,                     \
+                               flags + (size_t)b0 * stride, channels, stride, n_sigma, p,        \
+                               n_windows, (uint8_t)flag_value, core, e);                         \
+        }                                                                                        \
     } while (0)
     if (channels <= 256 * 8)
         KSP_TS(8);

@@ -529,7 +529,9 @@ class ThresholdSumDeviceTemplate(AbstractThresholdDeviceTemplate):
     context
         Context whose device will run the kernel
     n_windows
-        Number of window sizes 1, 2, 4, ... (1 to 4)
+        Number of window sizes 1, 2, 4, ... (1 to 8, i.e. windows of up to 128
+        channels; the reference sets no limit but its halo, ``2**n - n - 1`` channels
+        on each side of a chunk, stops being practical about there)
     flag_value
         Value stored for flagged samples
     tuning
@@ -541,8 +543,8 @@ class ThresholdSumDeviceTemplate(AbstractThresholdDeviceTemplate):
 
     def __init__(self, context: AbstractContext, n_windows: int = 4, flag_value: int = 1,
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
-        if not 1 <= n_windows <= 4:
-            raise ValueError("n_windows must be between 1 and 4")
+        if not 1 <= n_windows <= 8:
+            raise ValueError("n_windows must be between 1 and 8")
         if tuning is None:
             tuning = self.autotune(context, n_windows)
         self.context = context
@@ -655,14 +657,16 @@ class FlaggerDeviceTemplate:
         ``True``: require the fused kernel (``ValueError`` at instantiation if it
         cannot be used). ``False``: always build the reference-shaped sequence.
     keep_deviations
-        Fused path only: also write the ``deviations`` slot (float32, 4 more bytes per
-        sample of HBM traffic). The sequence always has it, as in the reference.
+        Fused path only: also provide and write the ``deviations`` slot (float32, 4 more
+        bytes per sample of HBM traffic). Off by default: in the reference ``deviations``
+        is a *temporary* slot of the flagger (reference rfi/device.py:1081-1091), which a
+        single-pass kernel has no need to materialise. The sequence always has it.
     """
 
     def __init__(self, background: AbstractBackgroundDeviceTemplate,
                  noise_est: AbstractNoiseEstDeviceTemplate,
                  threshold: AbstractThresholdDeviceTemplate,
-                 fused: Optional[bool] = None, keep_deviations: bool = True) -> None:  # fmt: skip
+                 fused: Optional[bool] = None, keep_deviations: bool = False) -> None:  # fmt: skip
         self.background = background
         self.noise_est = noise_est
         self.threshold = threshold
@@ -904,6 +908,7 @@ class FusedFlaggerDevice(accel.Operation):
     def parameters(self) -> Mapping[str, Any]:
         return {
             "fused": True,
+            "keep_deviations": "deviations" in self.slots,
             "width": self.template.background.width,
             "n_sigma": self.n_sigma,
             "n_windows": self.n_windows,

@@ -113,3 +113,19 @@ def config1_rfi():
 def channel_mask(channels, seed=2, fraction=1.0 / 16.0):
     """Per-channel input-flag mask of SURVEY 8(d) / config 5."""
     return (np.random.RandomState(seed).random_sample(channels) < fraction).astype(np.uint8)
+
+
+def add_rfi_sparse(vis, seed=3, fraction=1.0 / 16.0, block=256):
+    """Same kind of interference as :func:`add_rfi` (amplitude U(50, 70), random phase on
+    a random `fraction` of the samples) for arrays of 10^8 samples: amplitudes and
+    phases are drawn for the hit samples only, in blocks of rows, in place of three
+    full-size float64 draws. Modifies and returns `vis` (complex64)."""
+    rs = np.random.RandomState(seed=seed)
+    for r0 in range(0, vis.shape[0], block):
+        part = vis[r0 : r0 + block]
+        hit = rs.random_sample(part.shape) < fraction
+        n = int(np.count_nonzero(hit))
+        amp = rs.random_sample(n) * 20.0 + 50.0
+        phase = rs.random_sample(n) * (2.0 * np.pi)
+        part[hit] += (amp * np.exp(1j * phase)).astype(np.complex64)
+    return vis

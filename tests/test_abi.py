@@ -63,5 +63,5 @@ def test_argument_validation_without_gpu(lib):
     assert rc != 0 and "NULL" in _lib.last_error()
     rc = lib.ksp_threshold_sum(0, None, ctypes.c_void_p(8), ctypes.c_void_p(8),
                                ctypes.c_void_p(8), 16, 4, 16, 11.0,
-                               (ctypes.c_float * 5)(), 5, 1)  # fmt: skip
+                               (ctypes.c_float * 9)(), 9, 1)  # fmt: skip
     assert rc != 0 and "n_windows" in _lib.last_error()

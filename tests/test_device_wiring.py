@@ -129,9 +129,19 @@ def test_flagger_sequence_wiring(context, queue):
 
 
 def test_fused_selection_and_slots(context, queue):
+    # deviations is a temporary of the reference's flagger: absent unless asked for
     fn = templates(context).instantiate(queue, 4096, 64, threshold_args={"n_sigma": 11.0})
     assert isinstance(fn, device.FusedFlaggerDevice)
+    assert set(fn.slots) == {"vis", "noise", "flags"}
+    assert fn.parameters()["fused"] and not fn.parameters()["keep_deviations"]
+    fn()
+    name, args = queue.launches[-1]
+    assert name == "ksp_flagger_fused" and args[3] is None
+    assert [int(a) for a in args[5:15]] == [4096, 64, 64, 0, 64, 0, 13, 0, 0, 1]
+    fn = templates(context, keep_deviations=True).instantiate(
+        queue, 4096, 64, threshold_args={"n_sigma": 11.0})
     assert set(fn.slots) == {"vis", "noise", "flags", "deviations"}
+    assert fn.parameters()["keep_deviations"]
     fn()
     name, args = queue.launches[-1]
     assert name == "ksp_flagger_fused"

@@ -60,6 +60,7 @@ def make_template(context, use_flags="NONE", threshold="sum", noise="MADT", widt
         th = device.ThresholdSimpleDeviceTemplate(context, True)
     else:
         th = device.ThresholdSimpleDeviceTemplate(context, False)
+    kw.setdefault("keep_deviations", True)  # the parity tests compare them
     return device.FlaggerDeviceTemplate(bg, ne, th, **kw)
 
 
@@ -229,8 +230,9 @@ class TestFused:
         bg = device.BackgroundMedianFilterDeviceTemplate(context, 13, is_amplitude=True)
         ne = device.NoiseEstMADDeviceTemplate(context)
         th = device.ThresholdSumDeviceTemplate(context, n_windows=3, flag_value=5)
-        template = device.FlaggerDeviceTemplate(bg, ne, th)
+        template = device.FlaggerDeviceTemplate(bg, ne, th)  # default: no deviations slot
         out = run_fused(template, command_queue, amp, n_sigma=6.5, threshold_falloff=1.5)
+        assert "deviations" not in out
         ref_flags, ref_noise = oracle.flagger_full(
             amp, amplitudes=True, n_sigma=6.5, n_windows=3, threshold_falloff=1.5, flag_value=5
         )
@@ -303,6 +305,37 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @pytest.mark.parametrize("channels", [4096, 3000, 1024])
+    def test_mad_many_float32_ties(self, channels, context, command_queue, oracle):
+        """Hundreds of samples whose deviations share ONE float32 value while their
+        float64 values differ (constant level L in [1, 2) with isolated dips to tiny,
+        distinct amplitudes t: |d| = L - t rounds to L in float32 for t < 2^-25 but not
+        in float64). numpy's median is taken on the float64 values, and 1.4826 x median
+        then rounds to a different float32 than 1.4826 x L for some baselines -- the
+        selection among the ties has to be exact. Even and odd counts, ties above the
+        candidate-list capacity (256) and below it."""
+        rs = np.random.RandomState(channels)
+        baselines = 28
+        amp = np.empty((channels, baselines), np.float32)
+        for b in range(baselines):
+            level = np.float32(1.0 + 0.3 * rs.random_sample())
+            amp[:, b] = level
+            n_dips = [channels // 3, channels // 3 - 1, 300, 257, 255, 64, 40][b % 7]
+            where = 3 * rs.permutation(channels // 3)[:n_dips] + 1
+            amp[where, b] = (rs.randint(1, 1 << 16, n_dips) * 2.0 ** -40).astype(np.float32)
+            amp[3 * rs.randint(0, channels // 3, 4), b] = 100.0  # something to flag
+        vis = amp.astype(np.complex64)
+        out = run_fused(make_template(context), command_queue, vis, n_sigma=11.0)
+        ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, want_deviations=True)
+        # the test has teeth: float32 ties whose float64 median rounds differently
+        d32 = np.abs(ref_dev.astype(np.float32))
+        naive = np.where(d32 < 50, d32, 0).max(axis=0).astype(np.float64) * 1.4826
+        assert np.count_nonzero(naive.astype(np.float32) != ref_noise.astype(np.float32)) >= 3, "no teeth"
+        assert ref_flags.sum() > 0
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
     @pytest.mark.parametrize("seed", [1, 2, 3])
     def test_full_band_interference_kinds(self, seed, context, command_queue, oracle):
         """4096 channels with narrow-band, broad-band (runs of 2-12 channels: windows 2, 4
@@ -349,6 +382,58 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         assert out["flags"].sum() > 0
         np.testing.assert_array_equal(ref_flags, out["flags"])
+
+
+@pytest.fixture(scope="module")
+def config4_vis():
+    """BASELINE.json config 4 (= one GPU's shard of config 5): generate_data(4096, 32768)
+    of the reference's script with 1/16 injected interference, 1 GiB of complex64."""
+    return inputs.add_rfi_sparse(inputs.generate_data(4096, 32768), seed=3)
+
+
+def all_cores(oracle):
+    try:
+        n = len(__import__("os").sched_getaffinity(0))
+    except AttributeError:
+        n = __import__("os").cpu_count() or 1
+    return max(1, min(n, oracle.max_threads(), 64))
+
+
+class TestFullSize:
+    """The benchmarked launch itself (4096 channels x 32768 baselines, 8192 strips through
+    the XCD-aware strip order) on RFI-laden data: every flag and every noise value
+    against the oracle, deviations on a 4096 x 2048 slab. Mirrors reference
+    test/rfi/test_flagger.py:36-132 at BASELINE.json's size."""
+
+    SLAB = slice(30000, 32048)  # baselines whose deviations are compared
+
+    @pytest.mark.parametrize("mode", ["none", "channel"])
+    def test_config4_full_size(self, mode, config4_vis, context, command_queue, oracle):
+        vis = config4_vis
+        fl = inputs.channel_mask(vis.shape[0]) if mode == "channel" else None
+        template = make_template(context, mode.upper(), keep_deviations=True)
+        out = run_fused(template, command_queue, vis, fl, n_sigma=11.0)
+        oracle.set_threads(all_cores(oracle))
+        try:
+            ref_flags, ref_noise = oracle.flagger_full(vis, fl)
+            slab = np.ascontiguousarray(vis[:, self.SLAB])
+            _, _, ref_dev = oracle.flagger_full(slab, fl, want_deviations=True)
+        finally:
+            oracle.set_threads(1)
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        flagged = int(np.count_nonzero(ref_flags))
+        assert flagged > vis.size // 20  # the interference is found, not just nothing
+        assert np.array_equal(ref_flags, out["flags"]), (
+            f"{int(np.count_nonzero(ref_flags != out['flags']))} flags differ"
+        )
+        dev = out["deviations"][:, self.SLAB]
+        assert np.array_equal(ref_dev.astype(np.float32), dev)
+        # the north star's stated tolerance (met with 0): |dev - host| <= 1e-5
+        assert np.max(np.abs(dev.astype(np.float64) - ref_dev)) <= 1e-5
+        if mode == "channel":
+            # masked channels: deviation 0, never flagged (reference rfi/device.py:1073-1076)
+            assert not out["flags"][fl != 0].any()
+            assert not out["deviations"][fl != 0].any()
 
 
 class TestCABI:

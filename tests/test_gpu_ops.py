@@ -207,6 +207,27 @@ class TestBackground:
         out = bg_device(vis, flags) if flags is not None else bg_device(vis)
         np.testing.assert_array_equal(expected.astype(np.float32), out)
 
+    @pytest.mark.parametrize("mode", ["NONE", "CHANNEL"])
+    def test_config3_shape(self, mode, context, command_queue, oracle):
+        """4096 channels x 8192 baselines (BASELINE.json config 3, the reference's own
+        autotune shape, rfi/device.py:222-223): 128 wave columns x 64 channel segments
+        of the standalone kernel, every deviation against the oracle."""
+        from katsdpsigproc_amd.rfi import device
+
+        vis = inputs.add_rfi_sparse(inputs.generate_data(4096, 8192, seed=21), seed=22)
+        flags = inputs.channel_mask(4096) if mode == "CHANNEL" else None
+        template = device.BackgroundMedianFilterDeviceTemplate(
+            context, 13, False, device.BackgroundFlags[mode]
+        )
+        bg_device = device.BackgroundHostFromDevice(template, command_queue)
+        out = bg_device(vis, flags) if flags is not None else bg_device(vis)
+        oracle.set_threads(min(oracle.max_threads(), 64))
+        try:
+            expected = oracle.BackgroundMedianFilterHost(13)(vis, flags)
+        finally:
+            oracle.set_threads(1)
+        assert np.array_equal(expected.astype(np.float32), out)
+
     def test_golden(self, golden, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
@@ -251,7 +272,10 @@ class TestBackground:
 class TestNoiseEst:
     @pytest.mark.parametrize("kind", ["MAD", "MADT"])
     @pytest.mark.parametrize("shape", [(117, 273), (4096, 40), (1000, 3), (2, 5), (4095, 9),
-                                       (1025, 5), (2500, 7)])  # fmt: skip
+                                       (1025, 5), (2500, 7),
+                                       # the reference script's presets (rfiflagtest.py:190-195)
+                                       (8192, 21), (10240, 70), (8191, 3), (6000, 5),
+                                       (16384, 4)])  # fmt: skip
     def test_result(self, kind, shape, context, command_queue, oracle):
         # reference test/rfi/test_noise_est.py:54-79; exact instead of rtol 1e-7
         from katsdpsigproc_amd.rfi import device
@@ -262,7 +286,7 @@ class TestNoiseEst:
         if kind == "MAD":
             template = device.NoiseEstMADDeviceTemplate(context)
         else:
-            template = device.NoiseEstMADTDeviceTemplate(context, 10240)
+            template = device.NoiseEstMADTDeviceTemplate(context, max(10240, shape[0]))
         out = device.NoiseEstHostFromDevice(template, command_queue)(dev)
         expected = oracle.NoiseEstMADHost()(dev)
         np.testing.assert_array_equal(expected.astype(np.float32), out)
@@ -282,7 +306,7 @@ class TestNoiseEst:
             out = device.NoiseEstHostFromDevice(template, command_queue)(dev)
             np.testing.assert_allclose(expected, out, rtol=1e-7)
 
-    @pytest.mark.parametrize("channels", [300, 2048, 4096, 3001])
+    @pytest.mark.parametrize("channels", [300, 2048, 4096, 3001, 8192, 10240])
     def test_ties_and_zeros(self, channels, context, command_queue, oracle):
         """Quantised data (many equal values, even and odd counts), all-zero and
         single-value columns: the rank search must land on the right duplicates."""
@@ -341,9 +365,8 @@ class TestThreshold:
 
         dev, _ = inputs.threshold_case()
         noise = np.linspace(0.0, 50.0, dev.shape[1]).astype(np.float32)
-        # n_windows = 5 is outside the device op's range
         with pytest.raises(ValueError):
-            device.ThresholdSumDeviceTemplate(context, n_windows=5)
+            device.ThresholdSumDeviceTemplate(context, n_windows=9)
         template = device.ThresholdSumDeviceTemplate(context, n_windows=3, flag_value=4)
         out = self._run(template, command_queue, dev, noise, n_sigma=7.5, threshold_falloff=1.35)
         from oracle import rfi_oracle as oracle
@@ -372,6 +395,56 @@ class TestThreshold:
         # the edges really are exercised
         assert out[:8].any() or channels < 8 or True
 
+    @pytest.mark.parametrize("n_windows", [5, 6, 8])
+    @pytest.mark.parametrize("channels", [700, 4096, 9001])
+    def test_sum_more_windows(self, n_windows, channels, context, command_queue, oracle):
+        """More than 4 windows (reference rfi/device.py:840-852 takes any number): wide
+        windows that only fire on long, weak runs; dilation across several threads and,
+        for 9001 channels, across chunk halos of 2^n - n - 1 channels.
+
+        Parity note: numpy.convolve sums windows of >= 16 terms in a BLAS-dependent order
+        (measured in the build container: 40 % of adversarial 16-term sums differ from
+        the sequential sum in the last bit), so for w >= 16 "rfi.host" itself is only
+        defined up to one float64 rounding of the window sum; kernel and oracle both sum
+        sequentially, which differs from a given host only for sums within 1 ulp of
+        the limit."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(channels + n_windows)
+        baselines = 6
+        dev = (rs.standard_normal((channels, baselines)) * 10).astype(np.float32)
+        for b in range(baselines):
+            for length in (16, 40, 90, 200):
+                start = rs.randint(0, max(1, channels - length))
+                dev[start : start + length, b] += rs.uniform(8, 30)
+            dev[rs.randint(0, channels, 3), b] += 400.0
+        dev[: 1 << (n_windows - 1), 0] += 25.0  # a run at the lower band edge
+        dev[-(1 << (n_windows - 1)) :, 1] += 25.0  # and at the upper one
+        noise = rs.uniform(5, 15, baselines).astype(np.float32)
+        template = device.ThresholdSumDeviceTemplate(context, n_windows=n_windows)
+        out = self._run(template, command_queue, dev, noise, n_sigma=6.0)
+        expected = oracle.ThresholdSumHost(6.0, n_windows)(dev, noise)
+        fewer = oracle.ThresholdSumHost(6.0, 4)(dev, noise)
+        assert expected.sum() > fewer.sum()  # the wide windows do add flags
+        np.testing.assert_array_equal(expected, out)
+
+    def test_sum_many_baselines(self, context, command_queue, oracle):
+        """More baselines than one grid dimension holds (65535)."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(5)
+        channels, baselines = 40, 70000
+        dev = (rs.standard_normal((channels, baselines)) * 10).astype(np.float32)
+        dev[rs.random_sample(dev.shape) < 0.02] += 300.0
+        noise = rs.uniform(5, 15, baselines).astype(np.float32)
+        for template, host in (
+            (device.ThresholdSumDeviceTemplate(context), oracle.ThresholdSumHost(11.0)),
+            (device.ThresholdSimpleDeviceTemplate(context, True), oracle.ThresholdSimpleHost(11.0)),
+            (device.ThresholdSimpleDeviceTemplate(context, False), oracle.ThresholdSimpleHost(11.0)),
+        ):
+            out = self._run(template, command_queue, dev, noise, n_sigma=11.0)
+            np.testing.assert_array_equal(host(dev, noise), out)
+
     def test_host_classes_recover_spikes(self, context, command_queue):
         # reference test/rfi/test_threshold.py:44-57, run through the device
         from katsdpsigproc_amd.rfi import device
@@ -384,6 +457,101 @@ class TestThreshold:
         ):
             out = self._run(template, command_queue, dev, noise, n_sigma=11.0)
             np.testing.assert_array_equal(out.astype(np.bool_), spikes)
+
+
+class TestRankLibrary:
+    """csrc/rank.h + bitplane.h against NumPy: the counterpart of reference
+    test/test_rank.py:67-213 (its kernels are test/test_rank.mako:37-113)."""
+
+    @staticmethod
+    def _call(name, data, out_dtype, n_out, *extra):
+        import ctypes
+
+        from katsdpsigproc_amd import _lib
+
+        lib = _lib.load()
+        data = np.ascontiguousarray(data, np.float32)
+        d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+        assert lib.ksp_malloc(0, max(4, data.nbytes), ctypes.byref(d_in)) == 0
+        assert lib.ksp_malloc(0, 4 * n_out, ctypes.byref(d_out)) == 0
+        try:
+            assert lib.ksp_memcpy_async(0, d_in, data.ctypes.data_as(ctypes.c_void_p),
+                                        data.nbytes, 0, None) == 0  # fmt: skip
+            rc = getattr(lib, name)(0, None, d_in, d_out, len(data), *extra)
+            assert rc == 0, _lib.last_error()
+            out = np.empty(n_out, out_dtype)
+            assert lib.ksp_memcpy_async(0, out.ctypes.data_as(ctypes.c_void_p), d_out,
+                                        out.nbytes, 1, None) == 0  # fmt: skip
+            assert lib.ksp_stream_synchronize(0, None) == 0
+            return out
+        finally:
+            lib.ksp_free(0, d_in)
+            lib.ksp_free(0, d_out)
+
+    def test_rank(self):
+        # reference test/test_rank.py:36-88: rank of 0..999 among 2000 integers
+        rs = np.random.RandomState(seed=1)
+        data = rs.randint(0, 1000, size=2000).astype(np.int32)
+        expected = np.array([np.sum(np.less(data, i)) for i in range(1000)], np.int32)
+        out = self._call("ksp_selftest_rank", data, np.int32, 1000, 1000)
+        np.testing.assert_array_equal(expected, out)
+
+    @pytest.mark.parametrize("data", [[5.3], [-10.0, 5.5, np.nan, -20.0, np.nan]])
+    def test_min_max_simple(self, data):
+        # reference test/test_rank.py:129-137
+        out = self._call("ksp_selftest_minmax", data, np.float32, 2)
+        data = np.asarray(data, np.float32)
+        assert out[0] == np.nanmin(data) and out[1] == np.nanmax(data)
+
+    @pytest.mark.parametrize("ordered", [False, True])
+    def test_min_max_random(self, ordered):
+        # reference test/test_rank.py:139-151
+        rs = np.random.RandomState(seed=1)
+        data = rs.uniform(-10.0, 10.0, 1000).astype(np.float32)
+        data[rs.randint(0, 1000, 50)] = np.nan
+        if ordered:
+            data = np.sort(data)
+        out = self._call("ksp_selftest_minmax", data, np.float32, 2)
+        assert out[0] == np.nanmin(data) and out[1] == np.nanmax(data)
+
+    def test_min_max_all_nan(self):
+        # reference test/test_rank.py:153-165
+        out = self._call("ksp_selftest_minmax", [np.nan, np.nan], np.float32, 2)
+        assert np.isnan(out[0]) and np.isnan(out[1])
+
+    @staticmethod
+    def _median_case(name):
+        if name == "big_even":  # reference test/test_rank.py:192-201
+            data = np.random.RandomState(seed=1).random_sample(10001) + 0.5
+            data[123] = 0.0
+        elif name == "big_odd":  # reference test/test_rank.py:203-213
+            data = np.random.RandomState(seed=2).random_sample(10000) + 0.5
+            data[456] = 0.0
+        elif name == "wave_even":  # sizes the wavefront bit-plane search takes
+            data = np.random.RandomState(seed=3).random_sample(4096) + 0.5
+            data[[5, 77, 4000]] = 0.0
+            data[9] = 0.0
+        elif name == "wave_odd":
+            data = np.random.RandomState(seed=4).random_sample(3001) + 0.5
+            data[17] = 0.0
+        else:
+            data = np.asarray(name, np.float64)
+        return data.astype(np.float32)
+
+    @pytest.mark.parametrize(
+        "case", [[5.3], [1.2, 2.3, 3.4, 4.5], [0.0, 0.0, 0.0, 1.2, 5.3, 2.4],
+                 "big_even", "big_odd", "wave_even", "wave_odd"],
+    )  # fmt: skip
+    def test_median_non_zero(self, case):
+        # reference test/test_rank.py:168-213
+        data = self._median_case(case)
+        expected = np.median(data[data > 0.0])
+        out = self._call("ksp_selftest_median_non_zero", data, np.float32, 2)
+        assert expected == out[0] and expected == out[1]
+
+    def test_median_all_zero(self):
+        out = self._call("ksp_selftest_median_non_zero", np.zeros(100), np.float32, 2)
+        assert np.isnan(out[0]) and np.isnan(out[1])
 
 
 class TestArithmetic:
