@@ -158,13 +158,16 @@ int ksp_threshold_sum(int device, void *stream, const float *deviations, const f
  * amplitude is float64, so flags are bit-identical to rfi.host.FlaggerHost
  * (rfi/host.py:270-273). deviations (float32, [C][dev_stride]) and noise
  * (float32 [B]) are optional outputs (NULL to skip). scales64 is a HOST pointer
- * to n_windows doubles (falloff^-k, rfi/host.py:215). */
+ * to n_windows doubles (falloff^-k, rfi/host.py:215). workspace: NULL, or 64 bytes of
+ * device memory owned by the caller, zeroed once when allocated and used by one
+ * launch at a time (scheduling counters: with it the last strips of a large array are
+ * handed to whichever XCD is free; the kernel leaves it zeroed again). */
 int ksp_flagger_fused(int device, void *stream, const void *vis, const uint8_t *in_flags,
                       uint8_t *flags, float *deviations, float *noise, int channels,
                       int baselines, int vis_stride, int in_flags_stride, int flags_stride,
                       int dev_stride, int width, int is_amplitude, int flags_mode,
                       int threshold_kind, double n_sigma, const double *scales64, int n_windows,
-                      int flag_value);
+                      int flag_value, void *workspace);
 
 /* Arms two events (from ksp_event_create) for the calling thread's NEXT
  * ksp_flagger_fused call: they are recorded immediately before and after the flagger

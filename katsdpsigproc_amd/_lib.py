@@ -90,7 +90,7 @@ SIGNATURES = {
     "ksp_flagger_fused": [
         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, POINTER(c_double), c_int,
-        c_int,
+        c_int, c_void_p,
     ],
     "ksp_flagger_fused_supported": [c_int, c_int, c_int],
 }  # fmt: skip

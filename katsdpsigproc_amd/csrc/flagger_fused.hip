@@ -31,6 +31,13 @@
 
 #include <atomic>
 
+#ifndef FUSED_DYN_SHIFT
+#define FUSED_DYN_SHIFT 4  // the last 1 / 2^n of the strips are scheduled dynamically
+#endif
+#ifndef FUSED_STAGGER
+#define FUSED_STAGGER 2  // x 8128 cycles: how long the second workgroup of a CU waits once
+#endif
+
 // Events armed by ksp_flagger_fused_profile for the NEXT fused launch of this thread.
 static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 
@@ -44,16 +51,57 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int C = p.channels;
-    const int b0 = strip_of(blockIdx.x, p.n_strips) * FUSED_STRIP;
+    // Workgroups are dealt to the 8 XCDs round robin, blockIdx % 8, an equal share each --
+    // but the XCDs do not run equally fast (10 % between the fastest and the slowest in
+    // a traced launch), so with a static strip per workgroup the fast ones idle at the
+    // end. The last 1/16 of the strips are therefore handed out from a counter to twice
+    // as many workgroups as there are strips: an XCD that gets through its static share
+    // early takes more of them, a late one finds the counter exhausted and its surplus
+    // workgroups leave at once.
+    int strip;
+    const bool dynamic = (int)blockIdx.x >= p.n_static;
+    if (!dynamic) {
+        strip = strip_of(blockIdx.x, p.n_static);
+    } else {
+        int *slot = (int *)lds;
+        if (tid == 0) *slot = (int)atomicAdd(&p.work[0], 1u);
+        __syncthreads();
+        const int t = *slot;
+        __syncthreads();  // everybody has read the slot before the loader reuses it
+        strip = p.n_static + t;
+        if (t >= p.n_dyn) {
+            // nothing left: leave (the last dynamic workgroup to leave resets the counters)
+            if (tid == 0 && atomicAdd(&p.work[1], 1u) == (unsigned)p.dyn_blocks - 1u) {
+                p.work[0] = 0;
+                p.work[1] = 0;
+            }
+            return;
+        }
+    }
+    const int b0 = strip * FUSED_STRIP;
 
     // diagnostic time stamps (shader clock) of this wavefront's phases
     unsigned long long *trace = FUSED_DIAG_TRACE(p) ? FUSED_DIAG_TRACE(p) + ((size_t)blockIdx.x * FUSED_STRIP + wave) * 16 : nullptr;
     auto stamp = [&](int i) {
-        if (trace != nullptr && lane == 0) trace[i] = __builtin_amdgcn_s_memtime();
+        if (trace != nullptr && lane == 0) trace[i] = FUSED_DIAG_CLOCK();
     };
     if (trace != nullptr && lane == 0)
         trace[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
     stamp(0);
+#if FUSED_STAGGER > 0
+    // Two workgroups share a CU and start together, and they then STAY in step -- both
+    // loading (sharing the memory path), then both computing (sharing the vector ALUs)
+    // -- because each slows the other equally. Holding one of the pair back once, by
+    // about one LOAD phase, puts them in anti-phase for the rest of the launch (every
+    // later workgroup inherits the slot, and with it the phase, of the one it
+    // replaces): one's loads then run under the other's arithmetic. Which of the two
+    // waits is told by the hardware's workgroup slot number on the CU. Speed only.
+    if ((int)blockIdx.x < p.first_round &&
+        ((__builtin_amdgcn_s_getreg(63492 /* HW_REG_HW_ID */) >> 16) & 1)) {
+#pragma unroll
+        for (int i = 0; i < FUSED_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     bool masked = true;  // may the strip hold samples that take no part (NaN in LDS)?
     if (!p.is_amplitude && b0 + FUSED_STRIP <= p.baselines) {
         if (p.flags_mode == KSP_FLAGS_NONE)
@@ -136,6 +184,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     }
     write_flags(pa, fl, lane * R, bl, C);
     stamp(6);
+    if (dynamic && tid == 0 && atomicAdd(&pa.work[1], 1u) == (unsigned)pa.dyn_blocks - 1u) {
+        pa.work[0] = 0;
+        pa.work[1] = 0;
+    }
 }
 
 // =================================================================================
@@ -169,10 +221,10 @@ static int launch_fused(int device, hipStream_t s, const FusedParams &p)
         // diagnostic run: collect per-wavefront phase time stamps and dump them
         g_prof_start = g_prof_stop = nullptr;
         FusedParams pt = p;
-        const size_t n = (size_t)p.n_strips * FUSED_STRIP * 16;
+        const size_t n = (size_t)(p.n_static + p.dyn_blocks) * FUSED_STRIP * 16;
         KSP_CHECK(hipMalloc(&pt.trace, n * 8));
         KSP_CHECK(hipMemsetAsync(pt.trace, 0, n * 8, s));
-        hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, pt);
+        hipLaunchKernelGGL(kern, dim3(p.n_static + p.dyn_blocks), dim3(FUSED_THREADS), lds_bytes, s, pt);
         KSP_LAUNCH_CHECK();
         KSP_CHECK(hipStreamSynchronize(s));
         unsigned long long *host = (unsigned long long *)malloc(n * 8);
@@ -192,10 +244,11 @@ static int launch_fused(int device, hipStream_t s, const FusedParams &p)
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0 != nullptr)
-        hipExtLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, ev0, ev1,
-                              0, p);
+        hipExtLaunchKernelGGL(kern, dim3(p.n_static + p.dyn_blocks), dim3(FUSED_THREADS),
+                              lds_bytes, s, ev0, ev1, 0, p);
     else
-        hipLaunchKernelGGL(kern, dim3(p.n_strips), dim3(FUSED_THREADS), lds_bytes, s, p);
+        hipLaunchKernelGGL(kern, dim3(p.n_static + p.dyn_blocks), dim3(FUSED_THREADS), lds_bytes,
+                           s, p);
     KSP_LAUNCH_CHECK();
     return 0;
 }
@@ -219,7 +272,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
                                  int in_flags_stride, int flags_stride, int dev_stride, int width,
                                  int is_amplitude, int flags_mode, int threshold_kind,
                                  double n_sigma, const double *scales64, int n_windows,
-                                 int flag_value)
+                                 int flag_value, void *workspace)
 {
     KSP_REQUIRE(vis != nullptr && flags != nullptr, "NULL buffer");
     KSP_REQUIRE(channels >= 1 && baselines >= 0, "bad shape");
@@ -261,6 +314,20 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     p.n_windows = n_windows;
     p.flag_value = flag_value;
     p.n_strips = ksp_divup(baselines, FUSED_STRIP);
+    p.work = (unsigned *)workspace;
+    p.n_dyn = 0;
+    if (workspace != nullptr && p.n_strips >= 2048) p.n_dyn = (p.n_strips >> FUSED_DYN_SHIFT) & ~63;
+    p.n_static = p.n_strips - p.n_dyn;
+    p.dyn_blocks = 2 * p.n_dyn;
+    {
+        static std::atomic<int> cus[64];
+        int n = (device >= 0 && device < 64) ? cus[device].load(std::memory_order_relaxed) : 0;
+        if (n == 0) {
+            KSP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+            if (device >= 0 && device < 64) cus[device].store(n, std::memory_order_relaxed);
+        }
+        p.first_round = 2 * n;
+    }
 #ifdef KSP_DIAG
     p.trace = nullptr;
     {

@@ -17,6 +17,11 @@
 // Diagnostics (phase probes, per-wavefront time stamps) exist only in builds made with
 // KSP_EXTRA_HIPCC_FLAGS=-DKSP_DIAG (tools/phase_probe.py, tools/trace_phases.py); in the
 // product build these fold to constants and the code behind them disappears.
+#ifdef KSP_DIAG_REALTIME  // one 100 MHz clock for the whole chip (phases across CUs line up)
+#define FUSED_DIAG_CLOCK() __builtin_amdgcn_s_memrealtime()
+#else  // shader-clock cycles (fine-grained, per XCD)
+#define FUSED_DIAG_CLOCK() __builtin_amdgcn_s_memtime()
+#endif
 #ifdef KSP_DIAG
 #define FUSED_DIAG_STOP(p) ((p).debug_stop)
 #define FUSED_DIAG_TRACE(p) ((p).trace)
@@ -35,6 +40,12 @@ struct FusedParams {
     int vis_stride, in_flags_stride, flags_stride, dev_stride;
     int is_amplitude, flags_mode, threshold_kind, n_windows, flag_value;
     int n_strips;
+    // Schedule: workgroups 0 .. n_static-1 take strip strip_of(blockIdx); the remaining
+    // dyn_blocks workgroups take the last n_dyn strips from a counter, first come first
+    // served (n_dyn = 0 without a workspace). See flagger_fused.hip.
+    int n_static, n_dyn, dyn_blocks;
+    unsigned *work;  // [0] next dynamic strip, [1] dynamic workgroups finished; zero between launches
+    int first_round;  // workgroups resident at once (2 per CU): the first dispatch round
 #ifdef KSP_DIAG
     int debug_stop;  // diagnostic builds only (env KSP_FUSED_DEBUG_STOP): 0 = run everything
     unsigned long long *trace;  // diagnostic builds only (env KSP_FUSED_DEBUG_TRACE): phase time stamps
@@ -565,7 +576,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     int zeros;
     if constexpr (R != 64) zeros = count_less16<NP>(kp, 1);
     auto stamp = [&](int i) {
-        if (trace != nullptr && lane == 0) trace[i] = __builtin_amdgcn_s_memtime();
+        if (trace != nullptr && lane == 0) trace[i] = FUSED_DIAG_CLOCK();
     };
     stamp(8);
     if (debug_stop == 31) return (double)(kp[0] + kp[NP - 1]);
@@ -935,9 +946,50 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
     // Fast reject (exact): no window can fire unless some sample reaches
     // min_k thr_k; the 2^-20 margin makes the test conservative; needs thresholds > 0.
     const double cand = (double)thr_min * (1.0 - 0x1p-20);
-    const bool any = !(thr_min > 0.0f) || ((double)dmax >= cand);
+    const bool positive = thr_min > 0.0f;
+    const bool any = !positive || ((double)dmax >= cand);
     if (thr_nan || !__any(any)) return 0;
 
+    // Which samples can make a window fire? The host compares the sequential float64 sum
+    // of w values with w * thr_k (exact: w is a power of two), flagged samples standing
+    // in as exactly thr_k. Rounding is monotone, so a window whose values are all
+    // <= thr_k sums to <= w * thr_k and cannot fire: every firing window holds an
+    // UNFLAGGED sample whose exact deviation exceeds thr_k >= thr_min, and (rounding to
+    // float32 being monotone too) whose float32 deviation is >= thr_min. Two bit masks
+    // per lane -- `gt0`: float32 deviation > thr_0, which decides window 1 outright
+    // (d32 > thr_0 implies d > thr_0 for a float32 thr_0, d32 < thr_0 implies d < thr_0)
+    // -- and `ge`: deviation >= thr_min. Strong interference is all in gt0; when no lane
+    // has a sample in ge that is not in gt0, windows 2, 4, 8 have nothing to look at.
+    unsigned long long gt0, ge;
+    {
+        unsigned g_lo = 0, g_hi = 0, e_lo = 0, e_hi = 0;
+        const float t0 = thr[0], tm = thr_min;
+        // mask = 2 * mask + (compare): v_cmp into vcc, v_addc folds it in
+#pragma unroll
+        for (int j = (R < 32 ? R : 32) - 1; j >= 0; j--) {
+            asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(g_lo) : "v"(dev[j]), "v"(t0) : "vcc");
+            asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(e_lo) : "v"(dev[j]), "v"(tm) : "vcc");
+        }
+#pragma unroll
+        for (int j = R - 1; j >= 32; j--) {
+            asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(g_hi) : "v"(dev[j < R ? j : 0]), "v"(t0) : "vcc");
+            asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(e_hi) : "v"(dev[j < R ? j : 0]), "v"(tm) : "vcc");
+        }
+        gt0 = ((unsigned long long)g_hi << 32) | g_lo;
+        ge = ((unsigned long long)e_hi << 32) | e_lo;
+    }
+    // channels beyond the band hold deviation 0; with thresholds <= 0 everything is hot
+    const unsigned long long inband =
+        (c0 + R <= C) ? (R == 64 ? ~0ull : ((1ull << R) - 1))
+                      : (c0 >= C ? 0ull : ((1ull << (C - c0)) - 1));
+    if (positive && !__any(((ge & ~gt0) & inband) != 0)) return gt0 & inband;
+
+    // General case: some window may hold a weak sample. `hot` = unflagged samples that
+    // can still make a window fire (all of them when a threshold is not positive).
     float d[R];  // working copy: deviations with flagged samples replaced by thr
 #pragma unroll
     for (int j = 0; j < R; j++) d[j] = dev[j];
@@ -960,9 +1012,22 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
             const unsigned long long f = __shfl_down(fl, 1 + m / R, 64);
             nfl |= (unsigned)((f >> (m % R)) & 1) << m;
         }
+        // positions whose window [j, j + w) holds a hot sample, in any lane: only those
+        // are summed (a wave-uniform mask, so the skipping is done by the scalar unit)
+        unsigned long long need = ~0ull;
+        if (positive && R == 64) {
+            const unsigned long long hot = ge & ~fl;
+            const unsigned long long hot_next = __shfl_down(hot, 1, 64);
+            unsigned long long reach = hot;
+#pragma unroll
+            for (int m = 1; m < w; m++) reach |= (hot >> m) | (lane < 63 ? hot_next << (64 - m) : 0ull);
+            need = ((unsigned long long)ksp_wave_or_dpp((unsigned)(reach >> 32)) << 32) |
+                   ksp_wave_or_dpp((unsigned)reach);
+        }
         unsigned long long hits = 0, unsure = 0;
 #pragma unroll
         for (int j = 0; j < R; j++) {
+            if (!((need >> j) & 1)) continue;  // wave-uniform
             double s = 0.0, mag = 0.0;
 #pragma unroll
             for (int m = 0; m < w; m++) {
@@ -1002,7 +1067,7 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
         unsigned pin = 0;
         if (R >= 7) {
             const unsigned long long prev = __shfl_up(hits, 1, 64);
-            if (lane > 0) pin = (unsigned)(prev >> (R - 7)) & 0x7fu;
+            if (lane > 0) pin = (unsigned)(prev >> (R >= 7 ? R - 7 : 0)) & 0x7fu;
         } else {
 #pragma unroll
             for (int back = 1; back * R < 7 + R; back++) {

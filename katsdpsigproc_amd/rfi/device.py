@@ -860,6 +860,10 @@ class FusedFlaggerDevice(accel.Operation):
             self.slots["deviations"] = accel.IOSlot(
                 (channels, accel.Dimension(baselines)), np.float32
             )
+        # scheduling counters of the kernel (64 bytes, zeroed once; not a slot: nothing a
+        # caller could usefully bind)
+        self._workspace = accel.DeviceArray(command_queue.context, (16,), np.uint32)
+        self._workspace.zero(command_queue)
 
     def _run(self) -> None:
         bg = self.template.background
@@ -890,6 +894,7 @@ class FusedFlaggerDevice(accel.Operation):
                 self.scales,
                 np.int32(self.n_windows),
                 np.int32(self.template.threshold.flag_value),
+                self._workspace.buffer,
             ],
         )
 

@@ -62,6 +62,9 @@ class FakeQueue:
     def enqueue_read_buffer(self, buffer, data, blocking=True):
         data[...] = buffer.array
 
+    def enqueue_zero_buffer(self, buffer):
+        buffer.array[...] = 0
+
     def finish(self):
         pass
 

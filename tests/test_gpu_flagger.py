@@ -458,7 +458,7 @@ class TestCABI:
             scales = (ctypes.c_double * 4)(*[pow(1.2, -i) for i in range(4)])
             rc = lib.ksp_flagger_fused(
                 0, None, d_vis, None, d_flags, None, d_noise, channels, baselines, stride, 0,
-                stride, 0, 13, 0, 0, 1, 11.0, scales, 4, 1,
+                stride, 0, 13, 0, 0, 1, 11.0, scales, 4, 1, None,
             )  # fmt: skip
             assert rc == 0, _lib.last_error()
             flags = np.empty((channels, stride), np.uint8)

@@ -57,3 +57,9 @@ for k in np.unique(key)[::16]:
     only_comp += ((L == 0) & (Cc > 0)).sum(); idle += ((L == 0) & (Cc == 0)).sum()
 tot = both + only_load + only_comp + idle
 print(f"CU time: load+compute {both/tot:.2f}, load only {only_load/tot:.2f}, compute only {only_comp/tot:.2f}, idle {idle/tot:.2f}")
+# workgroup slot numbers (HW_ID bits 16-19) of the waves of that CU, in start order
+tg = (hwid >> 16) & 0xf
+wave_slot = hwid & 0xf
+print("tg_id / wave slot of the first 16 waves of the CU:", [(int(tg[i]), int(wave_slot[i])) for i in order[:16]])
+first = t[:, 0] < np.percentile(t[:, 0], 5)
+print("tg_id histogram of the earliest 5% of waves:", np.bincount(tg[first], minlength=16))
