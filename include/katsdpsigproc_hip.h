@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KSP_ABI_VERSION 1
+#define KSP_ABI_VERSION 2
 
 /* BackgroundFlags (reference: rfi/device.py:40-46) */
 #define KSP_FLAGS_NONE 0
@@ -118,10 +118,13 @@ int ksp_maskedsum_float(int device, void *stream, const void *in, const float *m
 /* background_median_filter (reference: rfi/background_median_filter.mako:200-220;
  * launch rfi/device.py:311-325). in: [C][stride] complex64 or float32 amplitudes;
  * out: [C][stride] float32 deviations; flags: [C] (CHANNEL) or [C][flags_stride]
- * (FULL) uint8, any non-zero value masks the sample. width must be odd, <= 63. */
+ * (FULL) uint8, any non-zero value masks the sample. width must be odd, <= 63.
+ * csplit: number of channel segments per baseline (the reference's tunable of the same
+ * name, rfi/device.py:212-252), 0 = let the launcher choose. */
 int ksp_background_median_filter(int device, void *stream, const void *in, float *out,
                                  const uint8_t *flags, int channels, int baselines, int stride,
-                                 int flags_stride, int width, int is_amplitude, int flags_mode);
+                                 int flags_stride, int width, int is_amplitude, int flags_mode,
+                                 int csplit);
 
 /* madnz_t (reference: rfi/madnz_t.mako:72-87; launch rfi/device.py:594-607).
  * in: [B][stride] float32; noise[b] = float32(1.4826 * median(|x| : x != 0)). */
@@ -146,10 +149,11 @@ int ksp_threshold_simple(int device, void *stream, const float *deviations, cons
  * threshold float32(float32(n_sigma * noise[b]) * scales[k]) -- the float32 chain
  * numpy's host class follows when noise is float32 (rfi/host.py:235,252). Sums
  * are float64 over full windows only (rfi/host.py:239-242). scales is a HOST
- * pointer to n_windows floats. */
+ * pointer to n_windows floats (n_windows <= 8). vt: channels per thread (the
+ * reference's tunable, rfi/device.py:868-887): 8, 16 or 32, 0 = let the launcher choose. */
 int ksp_threshold_sum(int device, void *stream, const float *deviations, const float *noise,
                       uint8_t *flags, int channels, int baselines, int stride, float n_sigma,
-                      const float *scales, int n_windows, int flag_value);
+                      const float *scales, int n_windows, int flag_value, int vt);
 
 /* Fused single-pass flagger: the MI355X-native form of FlaggerDevice
  * (reference: rfi/device.py:1062-1166 composes background -> [transpose] ->

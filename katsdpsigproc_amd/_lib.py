@@ -14,7 +14,7 @@ from ctypes import c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_native", "libkatsdpsigproc_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -76,7 +76,7 @@ SIGNATURES = {
     "ksp_selftest_median_non_zero": [c_int, c_void_p, c_void_p, c_void_p, c_int],
     "ksp_background_median_filter": [
         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-        c_int,
+        c_int, c_int,
     ],
     "ksp_madnz_t": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int],
     "ksp_madnz": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int],
@@ -85,7 +85,7 @@ SIGNATURES = {
     ],
     "ksp_threshold_sum": [
         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
-        POINTER(c_float), c_int, c_int,
+        POINTER(c_float), c_int, c_int, c_int,
     ],
     "ksp_flagger_fused": [
         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

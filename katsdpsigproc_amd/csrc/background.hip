@@ -98,11 +98,13 @@ __global__ __launch_bounds__(256) void background_kernel(
 template <int WIDTH>
 static int launch_background(hipStream_t s, const void *in, float *out, const uint8_t *flags,
                              int channels, int baselines, int stride, int flags_stride,
-                             int is_amplitude, int flags_mode)
+                             int is_amplitude, int flags_mode, int csplit)
 {
     const int wave_cols = ksp_divup(baselines, 64);
-    // Aim for >= 8192 wavefronts, segments of at least 4*WIDTH channels.
-    int want_segs = ksp_divup(8192, wave_cols);
+    // csplit = number of channel segments a baseline is cut into (each segment re-reads
+    // WIDTH - 1 channels of halo); 0: aim for >= 8192 wavefronts. Segments are at least
+    // 4 * WIDTH channels long either way.
+    int want_segs = csplit > 0 ? csplit : ksp_divup(8192, wave_cols);
     int seg_len = ksp_divup(channels, want_segs);
     if (seg_len < 4 * WIDTH) seg_len = 4 * WIDTH;
     if (seg_len > channels) seg_len = channels;
@@ -117,7 +119,7 @@ static int launch_background(hipStream_t s, const void *in, float *out, const ui
 extern "C" int ksp_background_median_filter(int device, void *stream, const void *in, float *out,
                                             const uint8_t *flags, int channels, int baselines,
                                             int stride, int flags_stride, int width,
-                                            int is_amplitude, int flags_mode)
+                                            int is_amplitude, int flags_mode, int csplit)
 {
     KSP_REQUIRE(in != nullptr && out != nullptr, "NULL buffer");
     KSP_REQUIRE(channels >= 0 && baselines >= 0 && stride >= baselines, "bad shape");
@@ -125,13 +127,14 @@ extern "C" int ksp_background_median_filter(int device, void *stream, const void
     KSP_REQUIRE(flags_mode >= KSP_FLAGS_NONE && flags_mode <= KSP_FLAGS_FULL, "bad flags_mode");
     KSP_REQUIRE(flags_mode == KSP_FLAGS_NONE || flags != nullptr, "flags buffer is NULL");
     KSP_REQUIRE(flags_mode != KSP_FLAGS_FULL || flags_stride >= baselines, "bad flags_stride");
+    KSP_REQUIRE(csplit >= 0, "csplit is negative");
     if (channels == 0 || baselines == 0) return 0;
     KSP_CHECK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
 #define KSP_BG(W)                                                                               \
     case W:                                                                                     \
         return launch_background<W>(s, in, out, flags, channels, baselines, stride, flags_stride, \
-                                    is_amplitude, flags_mode)
+                                    is_amplitude, flags_mode, csplit)
     switch (width) {
         KSP_BG(3);
         KSP_BG(5);

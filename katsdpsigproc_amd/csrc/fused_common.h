@@ -8,6 +8,9 @@
 #include "median_merge.h"
 #include "median_window.h"
 
+#ifndef FUSED_MAD_BITS
+#define FUSED_MAD_BITS 2  // bits decided per step of the MAD's key search (1 or 2)
+#endif
 #ifndef FUSED_STRIP
 #define FUSED_STRIP 4  // baselines per workgroup (one wavefront each); 4 -> two workgroups per CU
 #endif
@@ -631,17 +634,24 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             eq0 = g3 ? z11_0 : g2 ? z10_0 : g1 ? z01_0 : z00_0;
             eq1 = g3 ? z11_1 : g2 ? z10_1 : g1 ? z01_1 : z00_1;
         };
-#pragma unroll
-        for (int bit = 14; bit >= 2; bit -= 2) step2(bit, bit - 1);
-        {
-            const unsigned z0 = eq0 & np[0], z1 = eq1 & np[16];  // last bit on its own
+        // one bit: the keys that match the prefix and have this bit clear are counted
+        auto step1 = [&](int bit) {
+            const unsigned z0 = eq0 & np[bit], z1 = eq1 & np[16 + bit];
             const int c = below_bin + ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
             const bool take = c <= rank;
-            K |= take ? 1u : 0u;
+            K |= take ? (1u << bit) : 0u;
             below_bin = take ? c : below_bin;
             eq0 = take ? (eq0 ^ z0) : z0;
             eq1 = take ? (eq1 ^ z1) : z1;
-        }
+        };
+#if FUSED_MAD_BITS == 1
+#pragma unroll
+        for (int bit = 14; bit >= 0; bit--) step1(bit);
+#else
+#pragma unroll
+        for (int bit = 14; bit >= 2; bit -= 2) step2(bit, bit - 1);
+        step1(0);
+#endif
         in_bin = ksp_wave_sum_dpp(__popc(eq0) + __popc(eq1));
     } else {
         if (zeros == total) return __builtin_nan("");

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void threshold_sum_kernel(
 extern "C" int ksp_threshold_sum(int device, void *stream, const float *deviations,
                                  const float *noise, uint8_t *flags, int channels, int baselines,
                                  int stride, float n_sigma, const float *scales, int n_windows,
-                                 int flag_value)
+                                 int flag_value, int vt)
 {
     KSP_REQUIRE(deviations != nullptr && noise != nullptr && flags != nullptr, "NULL buffer");
     KSP_REQUIRE(scales != nullptr, "scales is NULL");
@@ -241,9 +241,15 @@ extern "C" int ksp_threshold_sum(int device, void *stream, const float *deviatio
                                n_windows, (uint8_t)flag_value, core, e);                         \
         }                                                                                        \
     } while (0)
-    if (channels <= 256 * 8)
+    // vt = channels per thread (8, 16 or 32: chunks of 2048, 4096 or 8192 channels); 0: the
+    // smallest that holds the baseline in one chunk (no halo), 32 beyond that
+    KSP_REQUIRE(vt == 0 || vt == 8 || vt == 16 || vt == 32, "vt must be 0, 8, 16 or 32");
+    if (vt == 0) vt = channels <= 256 * 8 ? 8 : channels <= 256 * 16 ? 16 : 32;
+    const int edge_all = (1 << n_windows) - n_windows - 1;
+    KSP_REQUIRE(channels <= 256 * vt || 256 * vt > 2 * edge_all, "chunk shorter than its halo");
+    if (vt == 8)
         KSP_TS(8);
-    else if (channels <= 256 * 16)
+    else if (vt == 16)
         KSP_TS(16);
     else
         KSP_TS(32);

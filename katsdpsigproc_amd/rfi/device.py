@@ -133,8 +133,11 @@ class BackgroundMedianFilterDeviceTemplate(AbstractBackgroundDeviceTemplate):
     use_flags
         :class:`BackgroundFlags`, or ``True``/``False`` for CHANNEL/NONE
     tuning
-        Accepted and ignored (``wgs``/``csplit`` of the reference): the gfx950 kernel
-        maps one wavefront to 64 baselines and picks the channel split itself.
+        ``csplit``: into how many channel segments a baseline is cut (each walked by its
+        own wavefront, re-reading ``width - 1`` channels of halo); 0 lets the launcher
+        choose. ``wgs`` of the reference has no counterpart: a wavefront always covers
+        64 adjacent baselines (512-byte coalesced rows). Default: autotuned and cached
+        (:mod:`katsdpsigproc_amd.tune`).
     """
 
     host_class = host.BackgroundMedianFilterHost
@@ -162,10 +165,41 @@ class BackgroundMedianFilterDeviceTemplate(AbstractBackgroundDeviceTemplate):
         self.kernel = context.native_kernel("ksp_background_median_filter")
 
     @classmethod
-    @tune.autotuner(test={"wgs": 128, "csplit": 4})
+    @tune.autotuner(test={"wgs": 64, "csplit": 4})
     def autotune(cls, context, width: int, is_amplitude: bool,
                  use_flags: BackgroundFlags) -> Mapping[str, Any]:  # fmt: skip
-        return {"wgs": 64, "csplit": 0}
+        """Search ``csplit`` on the reference's tuning shape, 4096 channels x 8192
+        baselines (reference rfi/device.py:215-252)."""
+        queue = context.create_tuning_command_queue()
+        channels, baselines = 4096, 8192
+        shape = (channels, baselines)
+        vis = accel.DeviceArray(context, shape, np.float32 if is_amplitude else np.complex64)
+        deviations = accel.DeviceArray(context, shape, np.float32)
+        rs = np.random.RandomState(seed=1)
+        if is_amplitude:
+            vis.set(queue, np.abs(rs.standard_normal(shape)).astype(np.float32))
+        else:
+            block = rs.standard_normal(shape + (2,)).astype(np.float32).view(np.complex64)[..., 0]
+            vis.set(queue, block)
+        flags = None
+        if use_flags == BackgroundFlags.CHANNEL:
+            flags = accel.DeviceArray(context, (channels,), np.uint8)
+            flags.set(queue, (rs.random_sample(channels) < 1 / 16).astype(np.uint8))
+        elif use_flags == BackgroundFlags.FULL:
+            flags = accel.DeviceArray(context, shape, np.uint8)
+            flags.set(queue, (rs.random_sample(shape) < 1 / 16).astype(np.uint8))
+
+        def generate(csplit: int):
+            fn = cls(context, width, is_amplitude, use_flags, tuning={"wgs": 64, "csplit": csplit})
+            op = fn.instantiate(queue, channels, baselines)
+            op.bind(vis=vis, deviations=deviations)
+            if flags is not None:
+                op.bind(flags=flags)
+            return tune.make_measure(queue, op)
+
+        # building a candidate compiles nothing here, so one thread will do
+        best = tune.autotune(generate, threads=1, csplit=[0, 8, 16, 32, 64, 128])
+        return {"wgs": 64, "csplit": int(best["csplit"])}
 
     def instantiate(self, command_queue: AbstractCommandQueue, channels: int, baselines: int,
                     allocator: Optional[AbstractAllocator] = None) -> "BackgroundMedianFilterDevice":  # fmt: skip
@@ -220,6 +254,7 @@ class BackgroundMedianFilterDevice(AbstractBackgroundDevice):
                 np.int32(self.template.width),
                 np.int32(self.template.is_amplitude),
                 np.int32(mode.value),
+                np.int32(self.template.tuning.get("csplit", 0)),
             ],
         )
 
@@ -227,6 +262,7 @@ class BackgroundMedianFilterDevice(AbstractBackgroundDevice):
         return {
             "width": self.template.width,
             "use_flags": self.template.use_flags.name,
+            "csplit": self.template.tuning.get("csplit", 0),
             "channels": self.channels,
             "baselines": self.baselines,
         }
@@ -535,7 +571,10 @@ class ThresholdSumDeviceTemplate(AbstractThresholdDeviceTemplate):
     flag_value
         Value stored for flagged samples
     tuning
-        Accepted and ignored (``wgs``/``vt`` of the reference).
+        ``vt``: channels per thread of the 256-thread workgroup (8, 16 or 32, i.e. chunks
+        of 2048, 4096 or 8192 channels with a ``2**n_windows - n_windows - 1`` channel
+        halo between chunks); 0 lets the launcher choose. ``wgs`` of the reference is
+        fixed at 256. Default: autotuned and cached (:mod:`katsdpsigproc_amd.tune`).
     """
 
     host_class = host.ThresholdSumHost
@@ -554,9 +593,30 @@ class ThresholdSumDeviceTemplate(AbstractThresholdDeviceTemplate):
         self.kernel = context.native_kernel("ksp_threshold_sum")
 
     @classmethod
-    @tune.autotuner(test={"wgs": 128, "vt": 3})
+    @tune.autotuner(test={"wgs": 256, "vt": 8})
     def autotune(cls, context: AbstractContext, n_windows: int) -> Mapping[str, Any]:
-        return {"wgs": 256, "vt": 16}
+        """Search ``vt`` on the reference's tuning shape, 4096 channels x 8192 baselines
+        with some interference to threshold (reference rfi/device.py:890-907)."""
+        queue = context.create_tuning_command_queue()
+        channels, baselines = 4096, 8192
+        shape = (baselines, channels)
+        rs = np.random.RandomState(seed=1)
+        dev = rs.standard_normal(shape).astype(np.float32)
+        dev[rs.random_sample(shape) < 0.01] += 100.0
+        deviations = accel.DeviceArray(context, shape, np.float32)
+        deviations.set(queue, dev)
+        noise = accel.DeviceArray(context, (baselines,), np.float32)
+        noise.set(queue, np.ones(baselines, np.float32))
+        flags = accel.DeviceArray(context, shape, np.uint8)
+
+        def generate(vt: int):
+            fn = cls(context, n_windows, tuning={"wgs": 256, "vt": vt})
+            op = fn.instantiate(queue, channels, baselines, 11.0)
+            op.bind(deviations=deviations, noise=noise, flags=flags)
+            return tune.make_measure(queue, op)
+
+        best = tune.autotune(generate, threads=1, vt=[8, 16, 32])
+        return {"wgs": 256, "vt": int(best["vt"])}
 
     def instantiate(self, command_queue: AbstractCommandQueue, channels: int, baselines: int,
                     n_sigma: float,
@@ -618,6 +678,7 @@ class ThresholdSumDevice(AbstractThresholdDevice):
                 self.scales,
                 np.int32(self.template.n_windows),
                 np.int32(self.template.flag_value),
+                np.int32(self.template.tuning.get("vt", 0)),
             ],
         )
 
@@ -625,6 +686,7 @@ class ThresholdSumDevice(AbstractThresholdDevice):
         return {
             "n_sigma": self.n_sigma,
             "threshold_falloff": self.threshold_falloff,
+            "vt": self.template.tuning.get("vt", 0),
             "flag_value": self.template.flag_value,
             "channels": self.channels,
             "baselines": self.baselines,

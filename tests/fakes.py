@@ -22,6 +22,8 @@ class FakeKernel:
 
 class FakeDevice:
     name = "fake"
+    platform_name = "fake platform"
+    driver_version = "0"
     simd_group_size = 64
 
 

@@ -37,7 +37,9 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_no_device_calls(lib):
-    assert lib.ksp_abi_version() == 1
+    from katsdpsigproc_amd import _lib
+
+    assert lib.ksp_abi_version() == _lib.ABI_VERSION == 2
     count = ctypes.c_int(-1)
     assert lib.ksp_device_count(ctypes.byref(count)) == 0
     assert count.value >= 0  # 0 in the CPU container
@@ -63,5 +65,5 @@ def test_argument_validation_without_gpu(lib):
     assert rc != 0 and "NULL" in _lib.last_error()
     rc = lib.ksp_threshold_sum(0, None, ctypes.c_void_p(8), ctypes.c_void_p(8),
                                ctypes.c_void_p(8), 16, 4, 16, 11.0,
-                               (ctypes.c_float * 9)(), 9, 1)  # fmt: skip
+                               (ctypes.c_float * 9)(), 9, 1, 0)  # fmt: skip
     assert rc != 0 and "n_windows" in _lib.last_error()

@@ -66,9 +66,14 @@ def test_background_op(context, queue):
     fn()
     name, args = queue.launches[-1]
     assert name == "ksp_background_median_filter"
-    # channels, baselines, stride, flags stride, width, amp, mode. vis, deviations and
-    # flags share one Dimension; its 128-element hint (uint8) exceeds 50, so no padding
-    assert [int(a) for a in args[3:]] == [100, 50, 50, 50, 13, 0, 2]
+    # channels, baselines, stride, flags stride, width, amp, mode, csplit (the stubbed
+    # autotuner's test value). vis, deviations and flags share one Dimension; its
+    # 128-element hint (uint8) exceeds 50, so no padding
+    assert [int(a) for a in args[3:]] == [100, 50, 50, 50, 13, 0, 2, 4]
+    assert fn.parameters()["csplit"] == 4
+    tuned = device.BackgroundMedianFilterDeviceTemplate(context, 13, tuning={"csplit": 32})
+    tuned.instantiate(queue, 100, 50)()
+    assert int(queue.launches[-1][1][-1]) == 32
     assert (fn.buffer("vis").padded_shape == fn.buffer("deviations").padded_shape
             == fn.buffer("flags").padded_shape == (100, 50))  # fmt: skip
     wide = t.instantiate(queue, 10, 200)
@@ -95,7 +100,7 @@ def test_noise_and_threshold_ops(context, queue):
     name, args = queue.launches[-1]
     assert name == "ksp_threshold_sum"
     assert list(args[7]) == [np.float32(1.0), np.float32(1 / 1.5), np.float32(1.5**-2)]
-    assert int(args[8]) == 3 and int(args[9]) == 4
+    assert int(args[8]) == 3 and int(args[9]) == 4 and int(args[10]) == 8  # vt: test value
     with pytest.raises(ValueError):
         device.ThresholdSumDeviceTemplate(context, n_windows=0)
     simple = device.ThresholdSimpleDeviceTemplate(context, True).instantiate(queue, 100, 7, 11.0)

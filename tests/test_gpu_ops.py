@@ -228,6 +228,29 @@ class TestBackground:
             oracle.set_threads(1)
         assert np.array_equal(expected.astype(np.float32), out)
 
+    @pytest.mark.parametrize("csplit", [0, 1, 3, 8, 64, 1000])
+    def test_every_channel_split(self, csplit, context, command_queue, oracle):
+        """The tunable only changes who computes what: any split gives the same bits."""
+        from katsdpsigproc_amd.rfi import device
+
+        vis_big, flags_big = inputs.background_case()
+        template = device.BackgroundMedianFilterDeviceTemplate(
+            context, 13, False, device.BackgroundFlags.FULL, tuning={"csplit": csplit}
+        )
+        out = device.BackgroundHostFromDevice(template, command_queue)(vis_big, flags_big)
+        expected = oracle.BackgroundMedianFilterHost(13)(vis_big, flags_big)
+        np.testing.assert_array_equal(expected.astype(np.float32), out)
+
+    @pytest.mark.force_autotune
+    def test_autotune(self, context):
+        # reference test/rfi/test_background.py test_autotune: the search runs and returns
+        # a configuration the launcher accepts
+        from katsdpsigproc_amd.rfi import device
+
+        t = device.BackgroundMedianFilterDeviceTemplate(context, 13)
+        assert t.tuning["csplit"] in (0, 8, 16, 32, 64, 128)
+        device.BackgroundMedianFilterDeviceTemplate(context, 5, True, device.BackgroundFlags.FULL)
+
     def test_golden(self, golden, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
@@ -427,6 +450,29 @@ class TestThreshold:
         fewer = oracle.ThresholdSumHost(6.0, 4)(dev, noise)
         assert expected.sum() > fewer.sum()  # the wide windows do add flags
         np.testing.assert_array_equal(expected, out)
+
+    @pytest.mark.parametrize("vt", [8, 16, 32])
+    @pytest.mark.parametrize("channels", [1500, 4096, 9001])
+    def test_sum_every_vt(self, vt, channels, context, command_queue, oracle):
+        """The tunable changes the chunking (and where halos fall), never the flags."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(channels + vt)
+        dev = (rs.standard_normal((channels, 5)) * 10).astype(np.float32)
+        dev[rs.random_sample(dev.shape) < 0.05] += 120.0
+        for b in range(5):
+            start = rs.randint(0, channels - 8)
+            dev[start : start + 8, b] += 75.0
+        noise = rs.uniform(5, 15, 5).astype(np.float32)
+        template = device.ThresholdSumDeviceTemplate(context, tuning={"vt": vt})
+        out = self._run(template, command_queue, dev, noise, n_sigma=11.0)
+        np.testing.assert_array_equal(oracle.ThresholdSumHost(11.0)(dev, noise), out)
+
+    @pytest.mark.force_autotune
+    def test_sum_autotune(self, context):
+        from katsdpsigproc_amd.rfi import device
+
+        assert device.ThresholdSumDeviceTemplate(context).tuning["vt"] in (8, 16, 32)
 
     def test_sum_many_baselines(self, context, command_queue, oracle):
         """More baselines than one grid dimension holds (65535)."""
