@@ -211,6 +211,23 @@ int ksp_selftest_minmax(int device, void *stream, const float *data, float *out,
 int ksp_selftest_median_non_zero(int device, void *stream, const float *data, float *out,
                                  int n);
 
+/* ---- run-time compilation and generic launch (reference abc.py:160-245 `compile`,
+ * 406-432 `enqueue_kernel`; cuda.py:182-187, 442-459) ----
+ * ksp_rtc_compile: compile HIP `source` with hiprtc for the device's architecture
+ *   (options: n_options strings such as "-DNAME=1", "-I/dir") and load it; *module_out
+ *   receives a module handle. The compiler's log (warnings, or the errors on failure)
+ *   is copied to `log` (NUL-terminated, at most log_capacity bytes; may be NULL).
+ * ksp_module_get_function: kernel `name` (an extern "C" __global__ function) of a module.
+ * ksp_launch_function: launch with grid/block given as 3 unsigned each (in workgroups /
+ *   threads) and kernel_params = array of pointers to the argument values, in order.
+ * ksp_module_unload: free the module. */
+int ksp_rtc_compile(int device, const char *source, const char *const *options, int n_options,
+                    void **module_out, char *log, size_t log_capacity);
+int ksp_module_get_function(int device, void *module, const char *name, void **function_out);
+int ksp_module_unload(int device, void *module);
+int ksp_launch_function(int device, void *stream, void *function, const unsigned *grid,
+                        const unsigned *block, unsigned shared_bytes, void **kernel_params);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,15 @@ SIGNATURES = {
         c_int, c_void_p,
     ],
     "ksp_flagger_fused_supported": [c_int, c_int, c_int],
+    "ksp_rtc_compile": [
+        c_int, c_char_p, POINTER(c_char_p), c_int, POINTER(c_void_p), c_char_p, c_size_t
+    ],
+    "ksp_module_get_function": [c_int, c_void_p, c_char_p, POINTER(c_void_p)],
+    "ksp_module_unload": [c_int, c_void_p],
+    "ksp_launch_function": [
+        c_int, c_void_p, c_void_p, POINTER(ctypes.c_uint), POINTER(ctypes.c_uint), ctypes.c_uint,
+        POINTER(c_void_p),
+    ],
 }  # fmt: skip
 
 _OTHER = {

@@ -6,9 +6,10 @@ RFI path touches (reference: src/katsdpsigproc/accel.py -- ``HostArray`` 368-456
 1297-1608, ``Operation`` 1611-1756, ``OperationSequence`` 1759-1835), written from that
 contract rather than from its code. Differences, all deliberate:
 
-* Kernels are compiled ahead of time into a C-ABI library, so :func:`build` (run-time
-  Mako rendering + compilation, reference accel.py:165-208) raises
-  :class:`NotImplementedError`; operations obtain kernels from :mod:`katsdpsigproc_amd.hip`.
+* The hot-path kernels are compiled ahead of time into a C-ABI library and operations
+  obtain them from :mod:`katsdpsigproc_amd.hip`; :func:`build` (template rendering +
+  run-time compilation through hiprtc, reference accel.py:165-208) serves the templated
+  utility operations and user kernels.
 * ``SVMArray`` / ``SVMAllocator`` and ``visualize_operation`` are outside the hot path
   and not provided.
 """
@@ -33,17 +34,66 @@ def roundup(x: int, y: int) -> int:
     return divup(x, y) * y
 
 
-def build(context, name, render_kws=None, extra_dirs=None, extra_flags=None, source=None):
-    """Not available: this package ships ahead-of-time compiled HIP kernels.
+KERNEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernels")
 
-    The reference renders a Mako template and compiles it at run time
-    (accel.py:165-208). Here every kernel lives in the native library and is reached
-    through :meth:`katsdpsigproc_amd.hip.Context.native_kernel`.
+
+def render_template(name, render_kws=None, extra_dirs=None, source=None) -> str:
+    """Text of kernel template `name` with `render_kws` filled in.
+
+    Templates are looked up in `extra_dirs`, then in the package's ``kernels/``
+    directory. ``*.mako`` files are rendered by Mako when it is installed (the
+    reference's format, accel.py:165-208); everything else uses ``${name}`` placeholders
+    (:class:`string.Template`), which needs no third-party package. ``simd_group_size``
+    (64 on gfx950) is always defined, as in the reference (accel.py:207). With `source`
+    the text is taken from there instead of a file.
     """
-    raise NotImplementedError(
-        "run-time kernel compilation is not part of the MI355X build; "
-        "use the operation templates, which bind ahead-of-time HIP kernels"
-    )
+    import string
+
+    keys = dict(render_kws or {})
+    dirs = [os.fspath(d) for d in (extra_dirs or [])] + [KERNEL_DIR]
+    if name.endswith(".mako") and source is None:
+        try:
+            from mako.lookup import TemplateLookup
+        except ImportError:
+            raise RuntimeError(
+                f"{name}: Mako is not installed; use a ${{name}}-style template "
+                "(kernels/*.hip.in) or install Mako"
+            ) from None
+        return TemplateLookup(dirs, strict_undefined=True).get_template(name).render(**keys)
+    if source is None:
+        for directory in dirs:
+            path = os.path.join(directory, name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    source = f.read()
+                break
+        else:
+            raise FileNotFoundError(f"kernel template {name} not found in {dirs}")
+    try:
+        return string.Template(source).substitute(keys)
+    except KeyError as exc:
+        raise KeyError(f"{name}: template parameter {exc} was not supplied") from None
+
+
+def build(context, name, render_kws=None, extra_dirs=None, extra_flags=None, source=None):
+    """Render kernel template `name` and compile it for `context` (reference
+    accel.py:165-208): returns a program whose ``get_kernel(name)`` gives kernels for
+    ``command_queue.enqueue_kernel(kernel, args, global_size, local_size)``.
+
+    The kernels of the RFI hot path do not come this way -- they are compiled ahead of
+    time into the native library; this is the route for the templated utility
+    operations (:mod:`~katsdpsigproc_amd.fill`, :mod:`~katsdpsigproc_amd.reduce`) and
+    for downstream kernels. ``kernels/port.h`` supplies the reference's portability
+    vocabulary (``KERNEL``, ``LOCAL_DECL``, ``BARRIER()``, ``get_global_id`` ...,
+    port.mako:19-116) so that such kernels keep their spelling.
+    """
+    keys = dict(render_kws or {})
+    keys.setdefault("simd_group_size", context.device.simd_group_size)
+    text = render_template(name, keys, extra_dirs, source)
+    flags = list(extra_flags or [])
+    for directory in list(extra_dirs or []) + [KERNEL_DIR]:
+        flags.append("-I" + os.fspath(directory))
+    return context.compile(text, flags)
 
 
 # --------------------------------------------------------------------------- devices

@@ -16,6 +16,7 @@ void ksp_set_error(const char *fmt, ...);
         if (_e != hipSuccess) {                                                            \
             ksp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                           __LINE__);                                                       \
+            (void)hipGetLastError(); /* reported here: do not leave it for a later launch check */ \
             return (int)_e;                                                                \
         }                                                                                  \
     } while (0)

@@ -103,6 +103,59 @@ class NativeProgram(AbstractProgram):
         return NativeKernel(self, name)
 
 
+def _unload_module(device_index: int, handle: int) -> None:
+    try:
+        _lib.call("ksp_module_unload", device_index, ctypes.c_void_p(handle))
+    except Exception:
+        pass
+
+
+class CompileError(RuntimeError):
+    """hiprtc rejected the source; ``log`` holds the compiler's messages."""
+
+    def __init__(self, message: str, log: str, source: str) -> None:
+        super().__init__(message + "\n" + log)
+        self.log = log
+        self.source = source
+
+
+class RtcKernel(AbstractKernel):
+    """One ``extern "C" __global__`` function of a run-time compiled program."""
+
+    def __init__(self, program: "RtcProgram", name: str) -> None:
+        handle = ctypes.c_void_p()
+        _lib.call("ksp_module_get_function", program.device_index,
+                  ctypes.c_void_p(program.handle), name.encode(), ctypes.byref(handle))  # fmt: skip
+        self.program = program  # keeps the module loaded
+        self.name = name
+        self.handle = handle.value
+
+
+class RtcProgram(AbstractProgram):
+    """HIP source compiled for this device by hiprtc (reference cuda.py:182-187 hands it
+    to nvcc through ``pycuda.compiler.SourceModule``)."""
+
+    LOG_BYTES = 1 << 16
+
+    def __init__(self, device_index: int, source: str, flags: Sequence[str]) -> None:
+        options = [f.encode() for f in flags]
+        array = (ctypes.c_char_p * max(1, len(options)))(*options)
+        handle = ctypes.c_void_p()
+        log = ctypes.create_string_buffer(self.LOG_BYTES)
+        try:
+            _lib.call("ksp_rtc_compile", device_index, source.encode(), array, len(options),
+                      ctypes.byref(handle), log, self.LOG_BYTES)  # fmt: skip
+        except RuntimeError as exc:
+            raise CompileError(str(exc), log.value.decode("utf-8", "replace"), source) from None
+        self.device_index = device_index
+        self.handle = handle.value
+        self.log = log.value.decode("utf-8", "replace")
+        self._finalizer = weakref.finalize(self, _unload_module, device_index, self.handle)
+
+    def get_kernel(self, name: str) -> RtcKernel:
+        return RtcKernel(self, name)
+
+
 class Event(AbstractEvent):
     """A recorded ``hipEvent_t`` (blocking-sync)."""
 
@@ -220,10 +273,11 @@ class Context(AbstractContext):
         return self.program.get_kernel(name)
 
     def compile(self, source: str, extra_flags: Optional[List[str]] = None) -> AbstractProgram:
-        raise NotImplementedError(
-            "run-time compilation (hiprtc) is not part of this build; kernels are "
-            "ahead-of-time HIP (SURVEY.md section 8(f), rank 1)"
-        )
+        """Compile HIP source for this device (hiprtc) -- for kernels that are not part
+        of the ahead-of-time library: the templated operations (fill, hreduce) and
+        user kernels. Raises :class:`CompileError` with the compiler's log."""
+        flags = ["-O3", "-std=c++17"] + list(extra_flags or [])
+        return RtcProgram(self._device.index, source, flags)
 
     def allocate_raw(self, n_bytes: int) -> RawBuffer:
         return RawBuffer(self._device.index, int(n_bytes))
@@ -358,15 +412,23 @@ class CommandQueue(AbstractCommandQueue):
 
     # -- kernels
     def enqueue_kernel(self, kernel, args, global_size=None, local_size=None) -> None:
-        """Launch a :class:`NativeKernel`.
+        """Launch a kernel.
 
-        `args` are the launcher's arguments after ``(device, stream)``; device buffers
-        may be passed as :class:`Buffer` objects (their address is used), as the
-        reference allows low-level arrays in `args` (abc.py:423-426). The launch geometry
-        is fixed inside the launcher, so `global_size`/`local_size` are ignored.
+        :class:`NativeKernel` (a launcher of the ahead-of-time library): `args` are the
+        launcher's arguments after ``(device, stream)``; the launch geometry is fixed
+        inside the launcher, so `global_size`/`local_size` are ignored.
+
+        :class:`RtcKernel` (run-time compiled): `args` are the kernel's arguments in
+        order -- :class:`Buffer` objects (their address is passed), ``None`` (a null
+        pointer) or numpy scalars (passed by value with exactly their dtype) -- and
+        `global_size`/`local_size` are the work sizes in *threads* per dimension, with
+        each global size a multiple of the local one (reference abc.py:406-432).
         """
+        if isinstance(kernel, RtcKernel):
+            self._enqueue_rtc(kernel, args, global_size, local_size)
+            return
         if not isinstance(kernel, NativeKernel):
-            raise TypeError("only NativeKernel objects can be enqueued on the HIP backend")
+            raise TypeError("not a kernel of the HIP backend")
         converted = []
         for arg in args:
             if isinstance(arg, Buffer):
@@ -380,6 +442,56 @@ class CommandQueue(AbstractCommandQueue):
             else:
                 converted.append(arg)
         _lib.call(kernel.name, self._dev, self._s, *converted)
+
+    _CTYPES = {
+        np.dtype(np.int8): ctypes.c_int8, np.dtype(np.uint8): ctypes.c_uint8,
+        np.dtype(np.int16): ctypes.c_int16, np.dtype(np.uint16): ctypes.c_uint16,
+        np.dtype(np.int32): ctypes.c_int32, np.dtype(np.uint32): ctypes.c_uint32,
+        np.dtype(np.int64): ctypes.c_int64, np.dtype(np.uint64): ctypes.c_uint64,
+        np.dtype(np.float32): ctypes.c_float, np.dtype(np.float64): ctypes.c_double,
+        np.dtype(np.bool_): ctypes.c_bool,
+    }  # fmt: skip
+
+    def _enqueue_rtc(self, kernel: RtcKernel, args, global_size, local_size) -> None:
+        if global_size is None or local_size is None:
+            raise ValueError("global_size and local_size are required for compiled kernels")
+        if len(global_size) != len(local_size) or not 1 <= len(global_size) <= 3:
+            raise ValueError("global_size and local_size must have 1 to 3 dimensions each")
+        grid, block = [], []
+        for g, l in zip(global_size, local_size):
+            if l <= 0 or g % l != 0:
+                raise ValueError("global size is not a multiple of the local size")
+            grid.append(g // l)
+            block.append(l)
+        if any(n == 0 for n in grid):
+            return  # nothing to do
+        grid += [1] * (3 - len(grid))
+        block += [1] * (3 - len(block))
+        values = []
+        for arg in args:
+            if isinstance(arg, Buffer):
+                values.append(ctypes.c_void_p(arg.ptr))
+            elif isinstance(arg, RawBuffer):
+                values.append(ctypes.c_void_p(arg.ptr))
+            elif arg is None:
+                values.append(ctypes.c_void_p(0))
+            elif isinstance(arg, np.generic):
+                if arg.dtype == np.complex64:
+                    values.append((ctypes.c_float * 2)(arg.real, arg.imag))
+                elif arg.dtype in self._CTYPES:
+                    values.append(self._CTYPES[arg.dtype](arg.item()))
+                else:
+                    raise TypeError(f"cannot pass a {arg.dtype} scalar to a kernel")
+            else:
+                raise TypeError(
+                    f"kernel argument {arg!r} is neither a device buffer nor a numpy scalar "
+                    "(plain Python numbers have no definite C type)"
+                )
+        params = (ctypes.c_void_p * max(1, len(values)))(
+            *[ctypes.cast(ctypes.pointer(v), ctypes.c_void_p) for v in values]
+        )
+        _lib.call("ksp_launch_function", self._dev, self._s, ctypes.c_void_p(kernel.handle),
+                  (ctypes.c_uint * 3)(*grid), (ctypes.c_uint * 3)(*block), 0, params)  # fmt: skip
 
     # -- synchronisation
     def enqueue_marker(self) -> Event:
