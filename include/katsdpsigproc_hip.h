@@ -228,6 +228,27 @@ int ksp_module_unload(int device, void *module);
 int ksp_launch_function(int device, void *stream, void *function, const unsigned *grid,
                         const unsigned *block, unsigned shared_bytes, void **kernel_params);
 
+/* ---- FFT over hipFFT (reference fft.py:64-202 binds cuFFT the same way) ----
+ * Transform types (the values hipFFT and cuFFT share). */
+#define KSP_FFT_R2C 0x2a
+#define KSP_FFT_C2R 0x2c
+#define KSP_FFT_C2C 0x29
+#define KSP_FFT_D2Z 0x6a
+#define KSP_FFT_Z2D 0x6c
+#define KSP_FFT_Z2Z 0x69
+/* ksp_fft_plan_create: batched plan of `rank` (1..3) dimensions n[], unit strides, with
+ *   padded (embedding) shapes and batch distances in elements on both sides
+ *   (hipfftMakePlanMany64; reference fft.py:304-323). Automatic work-area allocation is
+ *   off: *work_size bytes must be supplied to ksp_fft_exec.
+ * ksp_fft_exec: run the plan on `stream`; inverse selects the direction of C2C / Z2Z
+ *   (real transforms have only one). Unnormalised, like the reference. */
+int ksp_fft_plan_create(int device, int rank, const long long *n, const long long *inembed,
+                        long long idist, const long long *onembed, long long odist, int type,
+                        long long batch, void **plan_out, size_t *work_size);
+int ksp_fft_plan_destroy(int device, void *plan);
+int ksp_fft_exec(int device, void *stream, void *plan, int type, void *src, void *dest,
+                 void *work_area, int inverse);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,13 @@ SIGNATURES = {
     ],
     "ksp_module_get_function": [c_int, c_void_p, c_char_p, POINTER(c_void_p)],
     "ksp_module_unload": [c_int, c_void_p],
+    "ksp_fft_plan_create": [
+        c_int, c_int, POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong), ctypes.c_longlong,
+        POINTER(ctypes.c_longlong), ctypes.c_longlong, c_int, ctypes.c_longlong,
+        POINTER(c_void_p), POINTER(c_size_t),
+    ],
+    "ksp_fft_plan_destroy": [c_int, c_void_p],
+    "ksp_fft_exec": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
     "ksp_launch_function": [
         c_int, c_void_p, c_void_p, POINTER(ctypes.c_uint), POINTER(ctypes.c_uint), ctypes.c_uint,
         POINTER(c_void_p),

@@ -518,6 +518,12 @@ class CommandQueue(AbstractCommandQueue):
         _lib.call("ksp_stream_synchronize", self._dev, self._s)
         self._keepalive.clear()
 
+    def release_host_references(self) -> None:
+        """Forget the host arrays of asynchronous copies enqueued so far. For callers that
+        never :meth:`finish` a queue but know, from events they waited for, that those
+        copies are complete (a staging pipeline that owns its pinned buffers anyway)."""
+        self._keepalive.clear()
+
 
 class TuningCommandQueue(CommandQueue, AbstractTuningCommandQueue):
     """Times everything enqueued between :meth:`start_tuning` and :meth:`stop_tuning`."""

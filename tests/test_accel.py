@@ -17,9 +17,11 @@ class TestHelpers:
         assert accel.divup(10, 5) == 2 and accel.divup(11, 5) == 3 and accel.divup(0, 5) == 0
         assert accel.roundup(10, 5) == 10 and accel.roundup(11, 5) == 15
 
-    def test_build_is_not_available(self):
-        with pytest.raises(NotImplementedError):
-            accel.build(None, "transpose.mako")
+    def test_build_finds_its_templates(self):
+        # (compilation itself is exercised on the GPU in tests/test_build.py)
+        with pytest.raises(FileNotFoundError):
+            accel.render_template("no_such_kernel.hip.in", {})
+        assert "fill" in accel.render_template("fill.hip.in", {"wgs": 64, "ctype": "int"})
 
 
 class TestDimension:

@@ -209,5 +209,5 @@ def test_primitive_ops(context, queue):
 
 
 def test_accel_build_and_context_errors():
-    with pytest.raises(NotImplementedError):
-        accel.build(None, "x.mako")
+    with pytest.raises(FileNotFoundError):
+        accel.render_template("x.hip.in")

@@ -436,6 +436,54 @@ class TestFullSize:
             assert not out["deviations"][fl != 0].any()
 
 
+class TestStaging:
+    """Double-buffered host <-> device staging around the flagger (rfi/staging.py)."""
+
+    @pytest.mark.parametrize("mode, depth", [("none", 2), ("channel", 3), ("none", 1)])
+    def test_stream_of_blocks(self, mode, depth, context, oracle):
+        from katsdpsigproc_amd.rfi import staging
+
+        channels, baselines, n_blocks = 1024, 96, 7
+        template = make_template(context, mode.upper(), keep_deviations=False)
+        staged = staging.StagedFlagger(template, context, channels, baselines, depth=depth,
+                                       threshold_args=dict(n_sigma=11.0))  # fmt: skip
+        mask = inputs.channel_mask(channels) if mode == "channel" else None
+        blocks = [inputs.add_rfi(inputs.generate_data(channels, baselines, seed=100 + i), seed=i)
+                  for i in range(n_blocks)]  # fmt: skip
+        feed = [(b, mask) for b in blocks] if mask is not None else blocks
+        results = [(f.copy(), n.copy()) for f, n in staged.run(feed)]
+        assert len(results) == n_blocks
+        for block, (flags, noise) in zip(blocks, results):
+            ref_flags, ref_noise = oracle.flagger_full(block, mask)
+            np.testing.assert_array_equal(ref_flags, flags)
+            np.testing.assert_array_equal(ref_noise.astype(np.float32), noise)
+        staged.finish()
+
+    def test_zero_copy_producer_and_misuse(self, context, oracle):
+        from katsdpsigproc_amd.rfi import staging
+
+        template = make_template(context, keep_deviations=False)
+        staged = staging.StagedFlagger(template, context, 512, 40, depth=2,
+                                       threshold_args=dict(n_sigma=11.0))  # fmt: skip
+        with pytest.raises(RuntimeError):
+            staged.collect()  # nothing in flight
+        vis = inputs.add_rfi(inputs.generate_data(512, 40, seed=5), seed=6)
+        host_vis, host_flags = staged.host_buffers()
+        assert host_flags is None
+        host_vis[...] = vis  # the producer writes pinned memory directly
+        assert staged.submit() == 0
+        staged.submit(vis * 2)
+        with pytest.raises(RuntimeError):
+            staged.submit(vis)  # depth blocks already in flight
+        with pytest.raises(TypeError):
+            staging.StagedFlagger(template, context, 512, 40, threshold_args=dict(n_sigma=11.0)
+                                  ).submit(vis, np.zeros(512, np.uint8))  # fmt: skip
+        flags, _ = staged.collect()
+        np.testing.assert_array_equal(oracle.flagger_full(vis)[0], flags)
+        flags, _ = staged.collect()
+        np.testing.assert_array_equal(oracle.flagger_full(vis * 2)[0], flags)
+
+
 class TestCABI:
     """Call the C-ABI directly with ctypes: plain pointers and sizes, no accel layer."""
 
@@ -484,4 +532,4 @@ class TestCABI:
         assert "NULL" in _lib.last_error()
         with pytest.raises(RuntimeError):
             _lib.call("ksp_background_median_filter", 0, None, ctypes.c_void_p(8),
-                      ctypes.c_void_p(8), None, 4, 4, 4, 0, 4, 0, 0)  # fmt: skip
+                      ctypes.c_void_p(8), None, 4, 4, 4, 0, 4, 0, 0, 0)  # fmt: skip
