@@ -79,7 +79,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"{' '.join(cmd)}\n{proc.stdout}\n{proc.stderr}")
         return proc
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as pool:
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
         list(pool.map(run, jobs))
     if jobs or force or _stale(OUT, objects):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objects)

@@ -108,29 +108,36 @@ __global__ __launch_bounds__(256) void percentile5_wave_kernel(const void *__res
     auto plane = [&](int bit, int half) __attribute__((always_inline)) -> unsigned {
         return bit >= 16 ? hi[16 * half + bit - 16] : lo[16 * half + bit];
     };
-    auto select = [&](int rank) __attribute__((always_inline)) -> float {
-        PlaneSearch<decltype(plane)> s(rank, plane);
-        s.template step2<31, 30>();
-        s.template step2<29, 28>();
-        s.template step2<27, 26>();
-        s.template step2<25, 24>();
-        s.template step2<23, 22>();
-        s.template step2<21, 20>();
-        s.template step2<19, 18>();
-        s.template step2<17, 16>();
-        s.template step2<15, 14>();
-        s.template step2<13, 12>();
-        s.template step2<11, 10>();
-        s.template step2<9, 8>();
-        s.template step2<7, 6>();
-        s.template step2<5, 4>();
-        s.template step2<3, 2>();
-        s.template step2<1, 0>();
-        return key_to_float(s.prefix);
-    };
-    const float p25 = select((n_cols - 1) / 4);
-    const float p75 = select(((n_cols - 1) * 3) / 4);
-    const float p50 = select((n_cols - 1) / 2);
+    // The three order statistics are searched TOGETHER, bit pair by bit pair: the
+    // searches are independent, so each one's cross-lane reduction (a chain of dependent
+    // DPP steps) runs in the shadow of the other two instead of three chains end to end.
+    PlaneSearch<decltype(plane)> s25((n_cols - 1) / 4, plane);
+    PlaneSearch<decltype(plane)> s75(((n_cols - 1) * 3) / 4, plane);
+    PlaneSearch<decltype(plane)> s50((n_cols - 1) / 2, plane);
+#define KSP_P5_STEP(HI, LO)            \
+    s25.template step2<HI, LO>();      \
+    s75.template step2<HI, LO>();      \
+    s50.template step2<HI, LO>()
+    KSP_P5_STEP(31, 30);
+    KSP_P5_STEP(29, 28);
+    KSP_P5_STEP(27, 26);
+    KSP_P5_STEP(25, 24);
+    KSP_P5_STEP(23, 22);
+    KSP_P5_STEP(21, 20);
+    KSP_P5_STEP(19, 18);
+    KSP_P5_STEP(17, 16);
+    KSP_P5_STEP(15, 14);
+    KSP_P5_STEP(13, 12);
+    KSP_P5_STEP(11, 10);
+    KSP_P5_STEP(9, 8);
+    KSP_P5_STEP(7, 6);
+    KSP_P5_STEP(5, 4);
+    KSP_P5_STEP(3, 2);
+    KSP_P5_STEP(1, 0);
+#undef KSP_P5_STEP
+    const float p25 = key_to_float(s25.prefix);
+    const float p75 = key_to_float(s75.prefix);
+    const float p50 = key_to_float(s50.prefix);
     if (lane == 0) {
         out[0 * (size_t)out_stride + row] = key_to_float(kmin);
         out[1 * (size_t)out_stride + row] = key_to_float(kmax);

@@ -215,6 +215,32 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @pytest.mark.parametrize("width", [3, 5, 7, 9, 11, 15, 17, 19, 21])
+    @pytest.mark.parametrize("channels, baselines, mode",
+                             [(4096, 12, "none"), (4096, 8, "channel"), (1000, 9, "full"),
+                              (40, 5, "none")])  # fmt: skip
+    def test_other_widths(self, width, channels, baselines, mode, context, command_queue, oracle):
+        """Median windows other than the reference script's 13 (reference
+        rfi/device.py:141-262 takes any odd width): full band (merging median up to width
+        13, sorted window beyond), masked data, ragged shapes, bands shorter than a
+        window."""
+        rs = np.random.RandomState(width * 1000 + channels)
+        vis = inputs.add_rfi(inputs.generate_data(channels, baselines, seed=width), seed=width + 1,
+                             fraction=0.08)  # fmt: skip
+        fl = None
+        if mode == "channel":
+            fl = inputs.channel_mask(channels, seed=width)
+        elif mode == "full":
+            fl = (rs.random_sample(vis.shape) < 0.12).astype(np.uint8) * 2
+        template = make_template(context, mode.upper(), width=width)
+        out = run_fused(template, command_queue, vis, fl, n_sigma=9.0)
+        ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, fl, width=width, n_sigma=9.0,
+                                                            want_deviations=True)  # fmt: skip
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        assert ref_flags.sum() > 0
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
     def test_no_deviations_slot(self, context, command_queue, oracle):
         vis = inputs.add_rfi(inputs.generate_data(512, 40, seed=9), seed=10)
         template = make_template(context, keep_deviations=False)
@@ -359,7 +385,7 @@ class TestFused:
     def test_unsupported_falls_back_to_sequence(self, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
-        fn = make_template(context, width=5).instantiate(
+        fn = make_template(context, width=25).instantiate(
             command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
         )
         assert isinstance(fn, device.FlaggerDevice)
@@ -368,7 +394,7 @@ class TestFused:
         )
         assert isinstance(fn, device.FlaggerDevice)
         with pytest.raises(ValueError):
-            make_template(context, width=5, fused=True).instantiate(
+            make_template(context, width=25, fused=True).instantiate(
                 command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
             )
 
