@@ -159,10 +159,18 @@ class BackgroundMedianFilterDeviceTemplate(AbstractBackgroundDeviceTemplate):
         self.width = width
         self.is_amplitude = is_amplitude
         self.use_flags = use_flags
-        if tuning is None:
-            tuning = self.autotune(context, width, is_amplitude, use_flags)
-        self.tuning = dict(tuning)
+        # resolved on first use: a template that only ever feeds the fused flagger
+        # never launches this kernel and should not spend a second tuning it
+        self._tuning = dict(tuning) if tuning is not None else None
         self.kernel = context.native_kernel("ksp_background_median_filter")
+
+    @property
+    def tuning(self) -> Mapping[str, Any]:
+        if self._tuning is None:
+            self._tuning = dict(
+                self.autotune(self.context, self.width, self.is_amplitude, self.use_flags)
+            )
+        return self._tuning
 
     @classmethod
     @tune.autotuner(test={"wgs": 64, "csplit": 4})
@@ -584,13 +592,17 @@ class ThresholdSumDeviceTemplate(AbstractThresholdDeviceTemplate):
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
         if not 1 <= n_windows <= 8:
             raise ValueError("n_windows must be between 1 and 8")
-        if tuning is None:
-            tuning = self.autotune(context, n_windows)
         self.context = context
         self.n_windows = n_windows
         self.flag_value = flag_value
-        self.tuning = dict(tuning)
+        self._tuning = dict(tuning) if tuning is not None else None  # resolved on first use
         self.kernel = context.native_kernel("ksp_threshold_sum")
+
+    @property
+    def tuning(self) -> Mapping[str, Any]:
+        if self._tuning is None:
+            self._tuning = dict(self.autotune(self.context, self.n_windows))
+        return self._tuning
 
     @classmethod
     @tune.autotuner(test={"wgs": 256, "vt": 8})

@@ -1,35 +1,43 @@
 #!/bin/bash
 # Collect the round's judged profiles on the GPU box (run through gpurun):
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (kernel durations)
-#   2. separate --pmc passes (FETCH_SIZE / WRITE_SIZE / L2 hits) of the fused kernel
-# Results land in gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
-#   usage: tools/collect_profiles.sh <tag> [FLAGS mode: NONE|CHANNEL]
+#   2. separate --pmc passes (FETCH_SIZE / WRITE_SIZE / L2 hits / SQ counters) of the fused
+#      kernel, for use_flags NONE (config 4) and CHANNEL (the per-GPU launch of config 5)
+# Results land in gpurun_out/profiles_<tag>/ ; tools/publish_profiles.py copies what
+# should be judged into profiles/.      usage: tools/collect_profiles.sh <tag>
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.log 2>&1
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
-i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
-  i=$((i+1))
-  rm -rf /tmp/pm_$i
-  N=3 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm_$i -o p --output-format csv -- python3 $R/tools/run_fused.py > /tmp/pm_$i.log 2>&1
-  cp $(find /tmp/pm_$i -name "*counter_collection.csv" | head -1) $OUT/pmc_pass$i.csv
+for MODE in NONE CHANNEL; do
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
+    i=$((i+1))
+    rm -rf /tmp/pm_$i
+    FLAGS=$MODE N=3 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm_$i -o p --output-format csv -- python3 $R/tools/run_fused.py > /tmp/pm_$i.log 2>&1
+    cp $(find /tmp/pm_$i -name "*counter_collection.csv" | head -1) $OUT/pmc_${MODE}_pass$i.csv
+  done
+  rm -rf /tmp/kt_$MODE
+  FLAGS=$MODE N=12 rocprofv3 --kernel-trace --stats -d /tmp/kt_$MODE -o k --output-format csv -- python3 $R/tools/run_fused.py > /tmp/kt_$MODE.log 2>&1
+  cp $(find /tmp/kt_$MODE -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$MODE.csv
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(out + "/pmc_pass*.csv")):
-    for r in csv.DictReader(open(f)):
-        k = "fused" if "flagger_fused" in r["Kernel_Name"] else ("fill" if "fillBuffer" in r["Kernel_Name"] else None)
-        if k:
-            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-summary = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+summary = {}
+for mode in ("NONE", "CHANNEL"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(out + f"/pmc_{mode}_pass*.csv")):
+        for r in csv.DictReader(open(f)):
+            k = "fused" if "flagger_fused" in r["Kernel_Name"] else ("fill" if "fillBuffer" in r["Kernel_Name"] else None)
+            if k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summary[mode] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 json.dump(summary, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True))
 PY

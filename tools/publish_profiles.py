@@ -2,7 +2,7 @@
 """Copy a profile set collected by tools/collect_profiles.sh from gpurun_out/ into profiles/
 (the tracked, judged location) and refresh profiles/hbm_traffic.json.
 
-    usage: tools/publish_profiles.py <tag> <version>      e.g. r01c v3
+    usage: tools/publish_profiles.py <tag> <version>      e.g. r02a v1
 """
 import json
 import os
@@ -13,29 +13,33 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, ver = sys.argv[1], sys.argv[2]
 src = os.path.join(root, "gpurun_out", f"profiles_{tag}")
 rnd = tag[:3]
-shutil.copy(os.path.join(src, "bench_kernel_stats.csv"),
-            os.path.join(root, "profiles", f"{rnd}_bench_kernel_stats_{ver}.csv"))
+for name in ("bench_kernel_stats.csv", "kernel_stats_NONE.csv", "kernel_stats_CHANNEL.csv"):
+    shutil.copy(os.path.join(src, name),
+                os.path.join(root, "profiles", f"{rnd}_{name[:-4]}_{ver}.csv"))
 shutil.copy(os.path.join(src, "pmc_summary.json"),
             os.path.join(root, "profiles", f"{rnd}_pmc_summary_{ver}.json"))
 s = json.load(open(os.path.join(src, "pmc_summary.json")))
-f = s["fused"]
-# KB -> B, x2: gfx950 tallies 128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM section)
-fetch = f["FETCH_SIZE"] * 1024 * 2
-write = f["WRITE_SIZE"] * 1024
-entry = [{
-    "channels": 4096, "baselines": 32768, "use_flags": "NONE",
-    "kernel": "flagger_fused_kernel<64,13>",
-    "hbm_bytes_per_launch": round(fetch + write),
-    "fetch_bytes": round(fetch), "write_bytes": round(write),
-    "fill_kernel_write_bytes": round(s["fill"]["WRITE_SIZE"] * 1024),
-    "source": f"profiles/{rnd}_pmc_summary_{ver}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-              "passes; FETCH_SIZE doubled per the guide's gfx950 correction; cross-check "
-              f"TCC_EA0_RDREQ_sum x 128 B = {round(f['TCC_EA0_RDREQ_sum'] * 128)})",
-}]
-json.dump(entry, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
-print(open(os.path.join(src, "bench_kernel_stats.csv")).read())
-print(json.dumps(entry[0], indent=1))
-hit = f["TCC_HIT_sum"] / (f["TCC_HIT_sum"] + f["TCC_MISS_sum"])
-print(f"L2 hit rate {hit:.3f}; VALU instr {f['SQ_INSTS_VALU']:.4g} "
-      f"({f['SQ_INSTS_VALU'] * 64 / (4096 * 32768):.1f} per sample); VALU active "
-      f"{f['SQ_ACTIVE_INST_VALU'] * 4 / (f['SQ_BUSY_CYCLES'] / 32 * 1024):.2f} of SQ busy")
+entries = []
+for mode in ("NONE", "CHANNEL"):
+    f = s[mode]["fused"]
+    # KB -> B, x2: gfx950 tallies 128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM section)
+    fetch = f["FETCH_SIZE"] * 1024 * 2
+    write = f["WRITE_SIZE"] * 1024
+    entries.append({
+        "channels": 4096, "baselines": 32768, "use_flags": mode,
+        "kernel": "flagger_fused_kernel<64,13>",
+        "hbm_bytes_per_launch": round(fetch + write),
+        "fetch_bytes": round(fetch), "write_bytes": round(write),
+        "fill_kernel_write_bytes": round(s[mode]["fill"]["WRITE_SIZE"] * 1024),
+        "source": f"profiles/{rnd}_pmc_summary_{ver}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                  "passes; FETCH_SIZE doubled per the guide's gfx950 correction; cross-check "
+                  f"TCC_EA0_RDREQ_sum x 128 B = {round(f['TCC_EA0_RDREQ_sum'] * 128)})",
+    })
+    hit = f["TCC_HIT_sum"] / (f["TCC_HIT_sum"] + f["TCC_MISS_sum"])
+    print(f"{mode}: HBM {entries[-1]['hbm_bytes_per_launch'] / 1e9:.3f} GB/launch; L2 hit rate {hit:.3f}; "
+          f"VALU instr {f['SQ_INSTS_VALU']:.4g} ({f['SQ_INSTS_VALU'] * 64 / (4096 * 32768):.1f} per sample); "
+          f"VALU active {f['SQ_ACTIVE_INST_VALU'] * 4 / (f['SQ_BUSY_CYCLES'] / 32 * 1024):.2f} of SQ busy")
+json.dump(entries, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
+for name in ("bench_kernel_stats.csv", "kernel_stats_NONE.csv", "kernel_stats_CHANNEL.csv"):
+    print(name)
+    print(open(os.path.join(src, name)).read())
