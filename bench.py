@@ -280,6 +280,24 @@ def bringup_configs(context, queue, vis_host) -> dict:
         fn.buffer("vis").set(queue, block)
         key = "flagger_fused_4096x8192" if fused else "flagger_sequence_5_kernels_4096x8192"
         out[key] = entry(time_op(queue, fn), 9 * C * B, "9 B/sample")
+    del fn
+    # the reference script's wider presets (scripts/rfiflagtest.py:190-195): the same
+    # number of samples laid out as 8192 and 10240 channels (fused long-band kernels)
+    for channels in (8192, 10240):
+        baselines = (C * B) // channels
+        long_block = np.ascontiguousarray(block.reshape(-1)[: channels * baselines]).reshape(
+            channels, baselines)
+        template = device.FlaggerDeviceTemplate(
+            device.BackgroundMedianFilterDeviceTemplate(context, WIDTH),
+            device.NoiseEstMADTDeviceTemplate(context, 10240),
+            device.ThresholdSumDeviceTemplate(context),
+            fused=True,
+        )
+        fn = template.instantiate(queue, channels, baselines, threshold_args={"n_sigma": N_SIGMA})
+        fn.ensure_all_bound()
+        fn.buffer("vis").set(queue, long_block)
+        out[f"flagger_fused_{channels}x{baselines}"] = entry(
+            time_op(queue, fn), 9 * channels * baselines, "9 B/sample")
     return out
 
 

@@ -41,6 +41,10 @@ int ksp_fused_launch_w15_17(int width, int device, hipStream_t s, const FusedPar
 int ksp_fused_launch_w19_21(int width, int device, hipStream_t s, const FusedParams &p,
                             hipEvent_t ev0, hipEvent_t ev1);
 
+// more than 4096 channels (flagger_fused_long.hip)
+int ksp_fused_long_supported(int channels, int width);
+int ksp_fused_launch_long(int device, hipStream_t s, const FusedParams &p);
+
 static int ksp_fused_launch_other_width(int width, int device, hipStream_t s,
                                         const FusedParams &p, hipEvent_t ev0, hipEvent_t ev1)
 {
@@ -60,8 +64,9 @@ extern "C" int ksp_flagger_fused_profile(void *start_event, void *stop_event)
 
 extern "C" int ksp_flagger_fused_supported(int channels, int width, int n_windows)
 {
-    return channels >= 1 && channels <= 4096 && width >= 3 && width <= 21 && (width & 1) &&
-           n_windows >= 1 && n_windows <= 4;
+    if (n_windows < 1 || n_windows > 4) return 0;
+    if (channels > 4096) return ksp_fused_long_supported(channels, width);
+    return channels >= 1 && width >= 3 && width <= 21 && (width & 1);
 }
 
 extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
@@ -141,6 +146,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
         p.scales[k] = (scales64 != nullptr && k < n_windows) ? scales64[k] : 0.0;
 
     hipStream_t s = (hipStream_t)stream;
+    if (channels > 4096) return ksp_fused_launch_long(device, s, p);
     if (width != 13) return ksp_fused_launch_other_width(width, device, s, p, ev0, ev1);
     if (channels <= 64 * 4) return launch_fused<4, 13>(device, s, p, ev0, ev1);
     if (channels <= 64 * 16) return launch_fused<16, 13>(device, s, p, ev0, ev1);

@@ -107,15 +107,16 @@ struct MergeMedian {
                                              float &dmax)
     {
         run_src([&](int i) { return run[i]; }, [&](int i) { return run[i - RUN_GAP]; },
-                [&](int i) { return run[i + RUN_GAP]; }, lane, dev, dmax);
+                [&](int i) { return run[i + RUN_GAP]; }, lane == 0, lane == 63, dev, dmax);
     }
 
     // General form: in(i) is the lane's own sample i (0 <= i < R), left(i) (i < 0) and
-    // right(i) (i >= R) those of the neighbouring lanes -- asked for only where such a
-    // lane exists; beyond the band the +-inf stand-ins are supplied here.
+    // right(i) (i >= R) those of the neighbouring runs -- asked for only where such a
+    // run exists (`first` / `last`: this run is the first / last of the band); beyond the
+    // band the +-inf stand-ins are supplied here.
     template <class In, class Left, class Right>
-    __device__ __forceinline__ void run_src(In &&in, Left &&left, Right &&right, int lane,
-                                            float (&dev)[R], float &dmax)
+    __device__ __forceinline__ void run_src(In &&in, Left &&left, Right &&right, bool first,
+                                            bool last, float (&dev)[R], float &dmax)
     {
         pinf = __builtin_inff();
         ninf = -__builtin_inff();
@@ -123,8 +124,8 @@ struct MergeMedian {
         // sample i of the lane, -H <= i < R + H
         auto xs = [&](int i) -> float {
             if (i >= 0 && i < R) return in(i);
-            if (i < 0) return lane > 0 ? left(i) : (((-i) & 1) ? pinf : ninf);
-            return lane < 63 ? right(i) : (((i - R) & 1) ? ninf : pinf);
+            if (i < 0) return !first ? left(i) : (((-i) & 1) ? pinf : ninf);
+            return !last ? right(i) : (((i - R) & 1) ? ninf : pinf);
         };
         dmax = ninf;
         constexpr int STAGES = (R + W - 1) / W;
@@ -161,7 +162,7 @@ struct MergeMedian {
                     constexpr bool right_odd = j + H >= R && ((j + H - R + 1) & 1);
                     if constexpr (left_odd || right_odd) {
                         const float lo = rank<W - t, t, H - 1>(&S[off(t)], P);
-                        if (left_odd ? lane == 0 : lane == 63)
+                        if (left_odd ? first : last)
                             d = (float)((double)xc - ((double)lo + (double)med) * 0.5);
                     }
                     dmax = vmax(dmax, d);

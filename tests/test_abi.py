@@ -44,7 +44,10 @@ def test_abi_version_and_no_device_calls(lib):
     assert lib.ksp_device_count(ctypes.byref(count)) == 0
     assert count.value >= 0  # 0 in the CPU container
     assert lib.ksp_flagger_fused_supported(4096, 13, 4) == 1
-    assert lib.ksp_flagger_fused_supported(8192, 13, 4) == 0
+    assert lib.ksp_flagger_fused_supported(8192, 13, 4) == 1
+    assert lib.ksp_flagger_fused_supported(10240, 13, 4) == 1
+    assert lib.ksp_flagger_fused_supported(12289, 13, 4) == 0
+    assert lib.ksp_flagger_fused_supported(8192, 5, 4) == 0
     assert lib.ksp_flagger_fused_supported(4096, 5, 4) == 1
     assert lib.ksp_flagger_fused_supported(4096, 25, 4) == 0
     assert lib.ksp_flagger_fused_supported(4096, 12, 4) == 0

@@ -157,10 +157,10 @@ def test_fused_selection_and_slots(context, queue):
     assert set(lean.slots) == {"vis", "input_flags", "noise", "flags"}
     assert list(lean.scales) == [1.5**-i for i in range(4)]
     # falls back to the sequence when the fused kernel cannot do it
-    assert isinstance(templates(context).instantiate(queue, 8192, 8, threshold_args={"n_sigma": 1}),
+    assert isinstance(templates(context, noise_t=False).instantiate(queue, 16384, 8, threshold_args={"n_sigma": 1}),
                       device.FlaggerDevice)  # fmt: skip
     with pytest.raises(ValueError):
-        templates(context, fused=True).instantiate(queue, 8192, 8, threshold_args={"n_sigma": 1})
+        templates(context, noise_t=False, fused=True).instantiate(queue, 16384, 8, threshold_args={"n_sigma": 1})
     with pytest.raises(TypeError):
         templates(context).instantiate(queue, 64, 8)  # n_sigma missing
     with pytest.raises(TypeError):

@@ -241,6 +241,85 @@ class TestFused:
         assert ref_flags.sum() > 0
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @pytest.mark.parametrize(
+        "channels, baselines, mode",
+        [(8192, 9, "none"), (10240, 7, "none"), (8192, 5, "channel"), (10240, 4, "full"),
+         (4097, 6, "none"), (5000, 3, "full"), (9088, 5, "none"), (9089, 4, "none"),
+         (12288, 4, "none"), (12287, 2, "channel"), (8191, 9, "none")],
+    )  # fmt: skip
+    def test_long_bands(self, channels, baselines, mode, context, command_queue, oracle):
+        """More than 4096 channels (the reference script's 8192- and 10240-channel presets,
+        scripts/rfiflagtest.py:190-195): lanes own two or three runs of 64 channels;
+        strips of 4 baselines up to 9088 channels, of 3 beyond; whole and partial runs,
+        ragged strips, every input-flags mode; weak interference so that SumThreshold's
+        wider windows fire across run and group boundaries."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(channels + baselines)
+        vis = inputs.add_rfi(inputs.generate_data(channels, baselines, seed=3), seed=4, fraction=0.05)
+        for b in range(baselines):
+            for _ in range(10):
+                c = rs.randint(0, channels - 12)
+                w = rs.randint(1, 13)
+                vis[c : c + w, b] += rs.uniform(2.0, 9.0) * np.exp(2j * np.pi * rs.rand())
+        # interference straddling the group boundaries at 4096 and 8192
+        vis[4090:4100, 0] += 6.0
+        if channels > 8200:
+            vis[8188:8197, 1] += 5.0
+        fl = None
+        if mode == "channel":
+            fl = inputs.channel_mask(channels)
+        elif mode == "full":
+            fl = (rs.random_sample(vis.shape) < 0.1).astype(np.uint8) * 5
+        bg = device.BackgroundMedianFilterDeviceTemplate(context, 13, use_flags=device.BackgroundFlags[mode.upper()])
+        ne = device.NoiseEstMADTDeviceTemplate(context, 16384)
+        th = device.ThresholdSumDeviceTemplate(context)
+        template = device.FlaggerDeviceTemplate(bg, ne, th, keep_deviations=True)
+        out = run_fused(template, command_queue, vis, fl, n_sigma=7.0)
+        ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, fl, n_sigma=7.0, want_deviations=True)
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        assert ref_flags.sum() > 0
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
+    @pytest.mark.parametrize("channels", [8192, 10240])
+    def test_long_bands_degenerate(self, channels, context, command_queue, oracle):
+        """All-zero and constant baselines, heavy ties (crowded key bins, even and odd
+        counts), denormal-sized deviations, NaN and infinite visibilities at 8192 / 10240
+        channels, with Simple and Sum thresholds."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(channels)
+        baselines = 11
+        vis = inputs.generate_data(channels, baselines, seed=51)
+        vis[:, 0] = 0
+        vis[:, 1] = 3 + 4j
+        vis[:, 2] = (rs.randint(0, 4, channels) + 0j).astype(np.complex64)
+        vis[:, 3] = (rs.randint(0, 50, channels) * 0.25 + 0j).astype(np.complex64)
+        vis[100, 3] = 1000.0
+        vis[:, 4] = (rs.randint(0, 3, channels) * 1e-42 + 0j).astype(np.complex64)
+        vis[:, 5] = (rs.randint(0, 1000, channels) * 2.0 ** -10 + 0j).astype(np.complex64)
+        vis[::2, 6] = vis[1::2, 6]
+        vis[5000, 7] = np.nan
+        vis[4095, 8] = np.inf
+        level = np.float32(1.25)
+        vis[:, 9] = level
+        dips = 3 * rs.permutation(channels // 3)[:600] + 1
+        vis[dips, 9] = (rs.randint(1, 1 << 16, 600) * 2.0 ** -40).astype(np.float32)
+        for kind in ("sum", "simple"):
+            bg = device.BackgroundMedianFilterDeviceTemplate(context, 13)
+            ne = device.NoiseEstMADDeviceTemplate(context)
+            th = (device.ThresholdSumDeviceTemplate(context) if kind == "sum"
+                  else device.ThresholdSimpleDeviceTemplate(context, False))  # fmt: skip
+            template = device.FlaggerDeviceTemplate(bg, ne, th, keep_deviations=True)
+            out = run_fused(template, command_queue, vis, None, n_sigma=11.0)
+            with np.errstate(all="ignore"):
+                ref_flags, ref_noise, ref_dev = oracle.flagger_full(
+                    vis, threshold=kind, want_deviations=True)  # fmt: skip
+            np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+            np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+            np.testing.assert_array_equal(ref_flags, out["flags"])
+
     def test_no_deviations_slot(self, context, command_queue, oracle):
         vis = inputs.add_rfi(inputs.generate_data(512, 40, seed=9), seed=10)
         template = make_template(context, keep_deviations=False)
@@ -389,10 +468,10 @@ class TestFused:
             command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
         )
         assert isinstance(fn, device.FlaggerDevice)
-        fn = make_template(context).instantiate(
-            command_queue, 8192, 8, threshold_args=dict(n_sigma=11.0)
+        fn = make_template(context, noise="MAD").instantiate(
+            command_queue, 12289, 8, threshold_args=dict(n_sigma=11.0)
         )
-        assert isinstance(fn, device.FlaggerDevice)
+        assert isinstance(fn, device.FlaggerDevice)  # beyond the fused kernels' 12288 channels
         with pytest.raises(ValueError):
             make_template(context, width=25, fused=True).instantiate(
                 command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
