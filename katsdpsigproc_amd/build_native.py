@@ -68,7 +68,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources:
         obj = os.path.join(OUT_DIR, os.path.basename(src)[:-4] + ".o")
         objects.append(obj)
-        if force or _stale(obj, [src] + headers):
+        # (every source is a dependency of every object: one translation unit includes
+        # another's .hip file)
+        if force or _stale(obj, sources + headers):
             jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
 
     def run(cmd):

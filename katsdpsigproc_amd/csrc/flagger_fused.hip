@@ -43,7 +43,8 @@ int ksp_fused_launch_w19_21(int width, int device, hipStream_t s, const FusedPar
 
 // more than 4096 channels (flagger_fused_long.hip)
 int ksp_fused_long_supported(int channels, int width);
-int ksp_fused_launch_long(int device, hipStream_t s, const FusedParams &p);
+int ksp_fused_launch_long(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
+                          hipEvent_t ev1);
 
 static int ksp_fused_launch_other_width(int width, int device, hipStream_t s,
                                         const FusedParams &p, hipEvent_t ev0, hipEvent_t ev1)
@@ -146,7 +147,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
         p.scales[k] = (scales64 != nullptr && k < n_windows) ? scales64[k] : 0.0;
 
     hipStream_t s = (hipStream_t)stream;
-    if (channels > 4096) return ksp_fused_launch_long(device, s, p);
+    if (channels > 4096) return ksp_fused_launch_long(device, s, p, ev0, ev1);
     if (width != 13) return ksp_fused_launch_other_width(width, device, s, p, ev0, ev1);
     if (channels <= 64 * 4) return launch_fused<4, 13>(device, s, p, ev0, ev1);
     if (channels <= 64 * 16) return launch_fused<16, 13>(device, s, p, ev0, ev1);

@@ -1,4 +1,6 @@
 // Fused flagger for 4097 .. 12288 channels: see fused_long.h.
+#include <hip/hip_ext.h>
+
 #include <atomic>
 
 #include "fused_long.h"
@@ -13,9 +15,25 @@ __global__ __launch_bounds__(64 * S, 1) void flagger_long_kernel(const FusedPara
     const int C = p.channels;
     const int runs = (C + 63) >> 6;
     const int row_floats = runs * LONG_RUN + 8;
-    const int b0 = blockIdx.x * S;
+    // strips that share a 256-byte stretch of every row go to one XCD (as strip_of does
+    // for the 4096-channel kernel; 8 strips of 4 baselines, or of 3: then 96-byte groups)
+    const int b0 = strip_of(blockIdx.x, gridDim.x) * S;
 
-    const bool masked = load_strip_long<S>(p, lds, row_floats, runs, b0, tid);
+    bool masked;
+    if constexpr (S == 4) {
+      if (!p.is_amplitude && b0 + S <= p.baselines) {
+        if (p.flags_mode == KSP_FLAGS_NONE)
+            masked = load_strip_long_pairs<KSP_FLAGS_NONE>(p, lds, row_floats, runs, b0, tid);
+        else if (p.flags_mode == KSP_FLAGS_CHANNEL)
+            masked = load_strip_long_pairs<KSP_FLAGS_CHANNEL>(p, lds, row_floats, runs, b0, tid);
+        else
+            masked = load_strip_long_pairs<KSP_FLAGS_FULL>(p, lds, row_floats, runs, b0, tid);
+      } else {
+        masked = load_strip_long<S>(p, lds, row_floats, runs, b0, tid);
+      }
+    } else {
+        masked = load_strip_long<S>(p, lds, row_floats, runs, b0, tid);
+    }
     const bool any_masked = __syncthreads_or(masked);
 
     const int bl = b0 + wave;
@@ -87,7 +105,8 @@ __global__ __launch_bounds__(64 * S, 1) void flagger_long_kernel(const FusedPara
 }
 
 template <int NR, int S, int WIDTH>
-static int launch_long(int device, hipStream_t s, const FusedParams &p)
+static int launch_long(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
+                       hipEvent_t ev1)
 {
     const int runs = (p.channels + 63) >> 6;
     const size_t lds_bytes = sizeof(float) * S * (runs * LONG_RUN + 8) + sizeof(double) * 256 * S;
@@ -96,7 +115,11 @@ static int launch_long(int device, hipStream_t s, const FusedParams &p)
     // (the limit is set on every launch: it depends on the channel count)
     KSP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(ksp_divup(p.baselines, S)), dim3(64 * S), lds_bytes, s, p);
+    if (ev0 != nullptr)  // events of ksp_flagger_fused_profile: around the kernel itself
+        hipExtLaunchKernelGGL(kern, dim3(ksp_divup(p.baselines, S)), dim3(64 * S), lds_bytes, s,
+                              ev0, ev1, 0, p);
+    else
+        hipLaunchKernelGGL(kern, dim3(ksp_divup(p.baselines, S)), dim3(64 * S), lds_bytes, s, p);
     KSP_LAUNCH_CHECK();
     return 0;
 }
@@ -109,22 +132,25 @@ static int long_fits(int channels, int strip)
 }
 
 #ifdef KSP_LONG_THREE_GROUPS
-int ksp_fused_launch_long3(int device, hipStream_t s, const FusedParams &p)
+int ksp_fused_launch_long3(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
+                           hipEvent_t ev1)
 {
-    if (long_fits(p.channels, 4)) return launch_long<3, 4, 13>(device, s, p);
-    return launch_long<3, 3, 13>(device, s, p);
+    if (long_fits(p.channels, 4)) return launch_long<3, 4, 13>(device, s, p, ev0, ev1);
+    return launch_long<3, 3, 13>(device, s, p, ev0, ev1);
 }
 #else
-int ksp_fused_launch_long3(int device, hipStream_t s, const FusedParams &p);
+int ksp_fused_launch_long3(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
+                           hipEvent_t ev1);
 
 int ksp_fused_long_supported(int channels, int width)
 {
     return width == 13 && channels > 4096 && channels <= 12288 && long_fits(channels, 3);
 }
 
-int ksp_fused_launch_long(int device, hipStream_t s, const FusedParams &p)
+int ksp_fused_launch_long(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
+                          hipEvent_t ev1)
 {
-    if (p.channels <= 8192) return launch_long<2, 4, 13>(device, s, p);  // 4 x 8192 always fit
-    return ksp_fused_launch_long3(device, s, p);
+    if (p.channels <= 8192) return launch_long<2, 4, 13>(device, s, p, ev0, ev1);  // 4 x 8192 always fit
+    return ksp_fused_launch_long3(device, s, p, ev0, ev1);
 }
 #endif

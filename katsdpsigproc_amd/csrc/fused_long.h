@@ -84,6 +84,79 @@ __device__ __forceinline__ bool load_strip_long(const FusedParams &p, float *lds
     return (umax & 0x7fffffffu) > 0x7f800000u;
 }
 
+// Fast form for complex input and a whole strip of 4 baselines: two lanes per row, each
+// loading a pair of baselines (16 bytes), 128 rows per pass -- the loader of the
+// 4096-channel kernel (load_strip_fast) with this kernel's row layout.
+template <int MODE>
+__device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, float *lds,
+                                                      int row_floats, int runs, int b0, int tid)
+{
+    constexpr int LB = 4, NB = 3;
+    constexpr int RSTEP = 128;
+    constexpr int BATCH = RSTEP * LB;
+    const int C = p.channels;
+    const int q = tid & 1;
+    const int r0 = tid >> 1;
+    const int bl = b0 + 2 * q;
+    const float2 *vis = (const float2 *)p.vis + bl;
+    const size_t stride = (size_t)p.vis_stride;
+    float *row_a = lds + (2 * q) * row_floats, *row_b = lds + (2 * q + 1) * row_floats;
+    unsigned umax = 0;
+    auto request = [&](float4 (&raw)[LB], unsigned (&fl)[LB], int rbase) {
+#pragma unroll
+        for (int u = 0; u < LB; u++) {
+            const int row = min(rbase + r0 + u * RSTEP, C - 1);
+            raw[u] = *(const float4 *)(vis + (size_t)row * stride);
+            fl[u] = 0;
+            if (MODE == KSP_FLAGS_CHANNEL)
+                fl[u] = p.in_flags[row];
+            else if (MODE == KSP_FLAGS_FULL)
+                fl[u] = *(const unsigned short *)(p.in_flags + (size_t)row * p.in_flags_stride + bl);
+        }
+    };
+    auto finish = [&](const float4 (&raw)[LB], const unsigned (&fl)[LB], int rbase) {
+#pragma unroll
+        for (int u = 0; u < LB; u++) {
+            const int row = rbase + r0 + u * RSTEP;
+            float a0 = ksp_abs_c64(raw[u].x, raw[u].y);
+            float a1 = ksp_abs_c64(raw[u].z, raw[u].w);
+            if (MODE == KSP_FLAGS_CHANNEL) {
+                if (fl[u]) a0 = a1 = __builtin_nanf("");
+            } else if (MODE == KSP_FLAGS_FULL) {
+                if (fl[u] & 0xffu) a0 = __builtin_nanf("");
+                if (fl[u] >> 8) a1 = __builtin_nanf("");
+            }
+            umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
+            if (row < C) {
+                const int idx = long_index(row);
+                row_a[idx] = a0;
+                row_b[idx] = a1;
+            }
+        }
+    };
+    float4 buf[NB][LB];
+    unsigned fl[NB][LB];
+#pragma unroll
+    for (int k = 0; k < NB - 1; k++)
+        if (k * BATCH < C) request(buf[k], fl[k], k * BATCH);
+    for (int rb = 0; rb < C; rb += NB * BATCH) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int cur = rb + k * BATCH;
+            if (cur < C) {
+                const int ahead = cur + (NB - 1) * BATCH;
+                if (ahead < C) request(buf[(k + NB - 1) % NB], fl[(k + NB - 1) % NB], ahead);
+                finish(buf[k], fl[k], cur);
+            }
+        }
+    }
+    for (int row = C + r0; row < 64 * runs; row += RSTEP) {
+        row_a[long_index(row)] = __builtin_nanf("");
+        row_b[long_index(row)] = __builtin_nanf("");
+    }
+    return umax > 0x7f800000u;
+}
+
 // ---------------------------------------------------------------------------------
 // MAD over NR groups of 64 deviations per lane: 1.4826 x median of the non-zero |dev| of
 // the whole baseline. The search is mad_noise()'s bit-plane search with every count

@@ -137,14 +137,22 @@ def autotuner_impl(test: Mapping[str, Any], fn: Callable, *args: Any, **kwargs: 
     name = f"{cls.__module__}.{cls.__name__}.{fn.__name__}"
     table = name.replace(".", "_") + "__" + str(getattr(cls, "autotune_version", 0))
     columns = _key_columns(fn, args, kwargs)
-    conn = _open_db()
-    conn.row_factory = sqlite3.Row
+    try:
+        conn = _open_db()
+        conn.row_factory = sqlite3.Row
+    except (OSError, sqlite3.Error) as exc:
+        # an unwritable cache directory must not stop the computation: tune, do not record
+        _logger.warning("tuning cache unavailable (%s): tuning %s without it", exc, name)
+        return fn(*args, **kwargs)
     try:
         result = _fetch(conn, table, columns)
         if result is None:
             _logger.info("autotuning %s for %s", name, columns)
             result = fn(*args, **kwargs)
-            _save(conn, table, columns, {"value_" + k: v for k, v in result.items()})
+            try:
+                _save(conn, table, columns, {"value_" + k: v for k, v in result.items()})
+            except sqlite3.Error as exc:  # read-only or locked database: keep the result
+                _logger.warning("could not record the tuning of %s: %s", name, exc)
         else:
             _logger.debug("tuning cache hit for %s %s", name, columns)
     finally:

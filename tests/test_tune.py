@@ -188,6 +188,22 @@ def test_database_file_from_environment(tmp_path, monkeypatch):
     assert Tuned.autotune(make_context(), "p") == {"a": 9, "b": 8}
 
 
+def test_unusable_cache_does_not_stop_tuning(tmp_path, monkeypatch, caplog):
+    Tuned.calls, Tuned.answer, Tuned.fail = [], {"a": 2, "b": 3}, False
+    monkeypatch.setenv("KATSDPSIGPROC_TUNE_DB", str(tmp_path / "no" / "such" / "dir" / "t.db"))
+    assert Tuned.autotune(make_context(), "p") == {"a": 2, "b": 3}  # tuned, not recorded
+    assert Tuned.autotune(make_context(), "p") == {"a": 2, "b": 3}
+    assert len(Tuned.calls) == 2
+    # a database that can be read but not written
+    path = tmp_path / "ro.db"
+    monkeypatch.setenv("KATSDPSIGPROC_TUNE_DB", str(path))
+    sqlite3.connect(str(path)).close()
+    path.chmod(0o444)
+    import os
+    if os.geteuid() != 0:  # (root writes through the mode bits)
+        assert Tuned.autotune(make_context(), "q") == {"a": 2, "b": 3}
+
+
 def test_key_values_are_adapted_for_sqlite():
     import enum
 
