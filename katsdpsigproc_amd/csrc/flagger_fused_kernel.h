@@ -197,7 +197,6 @@ inline int launch_fused(int device, hipStream_t s, const FusedParams &p, hipEven
     const char *trace_path = getenv("KSP_FUSED_DEBUG_TRACE");
     if (trace_path != nullptr) {
         // diagnostic run: collect per-wavefront phase time stamps and dump them
-        g_prof_start = g_prof_stop = nullptr;
         FusedParams pt = p;
         const size_t n = (size_t)(p.n_static + p.dyn_blocks) * FUSED_STRIP * 16;
         KSP_CHECK(hipMalloc(&pt.trace, n * 8));
