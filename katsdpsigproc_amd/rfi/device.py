@@ -298,26 +298,49 @@ class NoiseEstHostFromDevice(host.AbstractNoiseEstHost):
 
 class NoiseEstMADDeviceTemplate(AbstractNoiseEstDeviceTemplate):
     """Median of non-zero absolute deviations on channel-major data
-    (reference rfi/device.py:363-409). :class:`NoiseEstMADTDeviceTemplate` is faster.
+    (reference rfi/device.py:363-409). :class:`NoiseEstMADTDeviceTemplate` is faster, as
+    the reference also notes (rfi/device.py:366).
 
-    `tuning` (``wgsx``/``wgsy``) is accepted and ignored.
+    `tuning`: ``method`` -- 0: the direct kernel (strips of 8 baselines through LDS up to
+    4096 channels; a column re-read per search pass beyond, as the reference does); 1:
+    transpose into a temporary ``deviations_t`` slot, then the baseline-major kernel
+    (one more pass over the data, but both passes are coalesced). Default: autotuned and
+    cached. ``wgsx``/``wgsy`` of the reference have no counterpart.
     """
 
     host_class = host.NoiseEstMADHost
     transposed = False
+    autotune_version = 2
 
     def __init__(self, context: AbstractContext,
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
-        if tuning is None:
-            tuning = self.autotune(context)
         self.context = context
-        self.tuning = dict(tuning)
+        self._tuning = dict(tuning) if tuning is not None else None  # resolved on first use
         self.kernel = context.native_kernel("ksp_madnz")
+        self.kernel_t = context.native_kernel("ksp_madnz_t")
+        self.kernel_transpose = context.native_kernel("ksp_transpose")
+
+    @property
+    def tuning(self) -> Mapping[str, Any]:
+        if self._tuning is None:
+            self._tuning = dict(self.autotune(self.context))
+        return self._tuning
 
     @classmethod
-    @tune.autotuner(test={"wgsx": 32, "wgsy": 8})
+    @tune.autotuner(test={"method": 0})
     def autotune(cls, context: AbstractContext) -> Mapping[str, Any]:
-        return {"wgsx": 64, "wgsy": 16}
+        queue = context.create_tuning_command_queue()
+        channels, baselines = 4096, 8192
+        rs = np.random.RandomState(seed=1)
+        data = rs.standard_normal((channels, baselines)).astype(np.float32)
+
+        def generate(method: int):
+            op = cls(context, tuning={"method": method}).instantiate(queue, channels, baselines)
+            op.ensure_all_bound()
+            op.buffer("deviations").set(queue, data)
+            return tune.make_measure(queue, op)
+
+        return {"method": int(tune.autotune(generate, threads=1, method=[0, 1])["method"])}
 
     def instantiate(self, command_queue: AbstractCommandQueue, channels: int, baselines: int,
                     allocator: Optional[AbstractAllocator] = None) -> "NoiseEstMADDevice":  # fmt: skip
@@ -331,6 +354,10 @@ class NoiseEstMADDevice(AbstractNoiseEstDevice):
 
     **deviations** : channels x baselines, float32
     **noise** : baselines, float32
+
+    .. rubric:: Temporary slots
+
+    **deviations_t** : baselines x channels, float32 (only with ``method`` 1)
     """
 
     transposed = False
@@ -343,13 +370,44 @@ class NoiseEstMADDevice(AbstractNoiseEstDevice):
         self.kernel = template.kernel
         self.channels = channels
         self.baselines = baselines
+        # the baseline-major kernel holds a row in one workgroup's registers
+        self.method = int(template.tuning.get("method", 0))
+        if channels > NoiseEstMADTDeviceTemplate.MAX_CHANNELS_SUPPORTED:
+            self.method = 0
         baselines_dim = accel.Dimension(baselines)
         self.slots["noise"] = accel.IOSlot((baselines_dim,), np.float32)
         self.slots["deviations"] = accel.IOSlot((channels, baselines_dim), np.float32)
+        if self.method == 1:
+            self.slots["deviations_t"] = accel.IOSlot((baselines, accel.Dimension(channels)), np.float32)
 
     def _run(self) -> None:
         deviations = self.buffer("deviations")
         noise = self.buffer("noise")
+        if self.method == 1:
+            dev_t = self.buffer("deviations_t")
+            self.command_queue.enqueue_kernel(
+                self.template.kernel_transpose,
+                [
+                    dev_t.buffer,
+                    deviations.buffer,
+                    np.int32(self.channels),
+                    np.int32(self.baselines),
+                    np.int32(dev_t.padded_shape[1]),
+                    np.int32(deviations.padded_shape[1]),
+                    np.int32(4),
+                ],
+            )
+            self.command_queue.enqueue_kernel(
+                self.template.kernel_t,
+                [
+                    dev_t.buffer,
+                    noise.buffer,
+                    np.int32(self.channels),
+                    np.int32(self.baselines),
+                    np.int32(dev_t.padded_shape[1]),
+                ],
+            )
+            return
         self.command_queue.enqueue_kernel(
             self.kernel,
             [
@@ -362,7 +420,7 @@ class NoiseEstMADDevice(AbstractNoiseEstDevice):
         )
 
     def parameters(self) -> Mapping[str, Any]:
-        return {"channels": self.channels, "baselines": self.baselines}
+        return {"channels": self.channels, "baselines": self.baselines, "method": self.method}
 
 
 class NoiseEstMADTDeviceTemplate(AbstractNoiseEstDeviceTemplate):

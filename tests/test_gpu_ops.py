@@ -314,6 +314,28 @@ class TestNoiseEst:
         expected = oracle.NoiseEstMADHost()(dev)
         np.testing.assert_array_equal(expected.astype(np.float32), out)
 
+    @pytest.mark.parametrize("shape", [(117, 273), (4096, 40), (1000, 3), (8192, 21), (16384, 4),
+                                       (20000, 3)])  # fmt: skip
+    def test_transposing_method(self, shape, context, command_queue, oracle):
+        """Channel-major input through transpose + the baseline-major kernel (tuning
+        ``method`` 1); beyond 16384 channels the direct kernel is used whatever is asked."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(seed=2)
+        dev = rs.standard_normal(shape).astype(np.float32)
+        dev[rs.random_sample(shape) < 0.1] = 0.0
+        template = device.NoiseEstMADDeviceTemplate(context, tuning={"method": 1})
+        fn = template.instantiate(command_queue, *shape)
+        assert ("deviations_t" in fn.slots) == (shape[0] <= 16384)
+        out = device.NoiseEstHostFromDevice(template, command_queue)(dev)
+        np.testing.assert_array_equal(oracle.NoiseEstMADHost()(dev).astype(np.float32), out)
+
+    @pytest.mark.force_autotune
+    def test_autotune(self, context):
+        from katsdpsigproc_amd.rfi import device
+
+        assert device.NoiseEstMADDeviceTemplate(context).tuning["method"] in (0, 1)
+
     def test_known_answer(self, context, command_queue):
         # reference test/rfi/test_noise_est.py:35-50
         from katsdpsigproc_amd.rfi import device
