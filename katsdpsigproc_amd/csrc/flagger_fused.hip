@@ -125,7 +125,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     p.n_dyn = 0;
     if (workspace != nullptr && p.n_strips >= 2048) p.n_dyn = (p.n_strips >> FUSED_DYN_SHIFT) & ~63;
     p.n_static = p.n_strips - p.n_dyn;
-    p.dyn_blocks = 2 * p.n_dyn;
+    p.dyn_blocks = p.n_dyn * FUSED_DYN_OVER / 4;
     {
         static std::atomic<int> cus[64];
         int n = (device >= 0 && device < 64) ? cus[device].load(std::memory_order_relaxed) : 0;

@@ -13,6 +13,9 @@
 #ifndef FUSED_DYN_SHIFT
 #define FUSED_DYN_SHIFT 4  // the last 1 / 2^n of the strips are scheduled dynamically
 #endif
+#ifndef FUSED_DYN_OVER
+#define FUSED_DYN_OVER 8  // quarters: dynamic workgroups launched per dynamic strip (8 = 2x)
+#endif
 #ifndef FUSED_STAGGER
 #define FUSED_STAGGER 2  // x 8128 cycles: how long the second workgroup of a CU waits once
 #endif

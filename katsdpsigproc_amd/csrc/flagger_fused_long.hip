@@ -112,9 +112,15 @@ static int launch_long(int device, hipStream_t s, const FusedParams &p, hipEvent
     const size_t lds_bytes = sizeof(float) * S * (runs * LONG_RUN + 8) + sizeof(double) * 256 * S;
     KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines, s));
     auto kern = flagger_long_kernel<NR, S, WIDTH>;
-    // (the limit is set on every launch: it depends on the channel count)
-    KSP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes));
+    // opt in once per device to the whole 160 KiB (the size in use depends on the channel count)
+    static std::atomic<bool> attr_set[64];
+    if (device < 0 || device >= 64 || !attr_set[device].load(std::memory_order_acquire)) {
+        hipFuncAttributes fa;
+        KSP_CHECK(hipFuncGetAttributes(&fa, (const void *)kern));
+        KSP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - (int)fa.sharedSizeBytes));
+        if (device >= 0 && device < 64) attr_set[device].store(true, std::memory_order_release);
+    }
     if (ev0 != nullptr)  // events of ksp_flagger_fused_profile: around the kernel itself
         hipExtLaunchKernelGGL(kern, dim3(ksp_divup(p.baselines, S)), dim3(64 * S), lds_bytes, s,
                               ev0, ev1, 0, p);

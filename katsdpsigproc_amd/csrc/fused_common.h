@@ -9,7 +9,7 @@
 #include "median_window.h"
 
 #ifndef FUSED_MAD_BITS
-#define FUSED_MAD_BITS 2  // bits decided per step of the MAD's key search (1 or 2)
+#define FUSED_MAD_BITS 1  // bits decided per step of the MAD's key search (1 or 2)
 #endif
 #ifndef FUSED_STRIP
 #define FUSED_STRIP 4  // baselines per workgroup (one wavefront each); 4 -> two workgroups per CU
@@ -236,17 +236,20 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
         }
     };
     auto finish = [&](const float4 (&raw)[LB], const unsigned (&fl)[LB], int rbase) {
+        float amp[LB][2];
+        if (FUSED_DIAG_STOP(p) == 11) {  // diagnostic: how long does the loader take without arithmetic?
+#pragma unroll
+            for (int u = 0; u < LB; u++) {
+                amp[u][0] = raw[u].x;
+                amp[u][1] = raw[u].z;
+            }
+        } else {
+            ksp_abs_c64_batch<LB>(raw, amp);
+        }
 #pragma unroll
         for (int u = 0; u < LB; u++) {
             const int row = rbase + r0 + u * RSTEP;
-            float a0, a1;
-            if (FUSED_DIAG_STOP(p) == 11) {  // diagnostic: how long does the loader take without arithmetic?
-                a0 = raw[u].x;
-                a1 = raw[u].z;
-            } else {
-                a0 = ksp_abs_c64(raw[u].x, raw[u].y);
-                a1 = ksp_abs_c64(raw[u].z, raw[u].w);
-            }
+            float a0 = amp[u][0], a1 = amp[u][1];
             if (MODE == KSP_FLAGS_CHANNEL) {
                 if (fl[u]) a0 = a1 = __builtin_nanf("");
             } else if (MODE == KSP_FLAGS_FULL) {

@@ -115,11 +115,12 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
         }
     };
     auto finish = [&](const float4 (&raw)[LB], const unsigned (&fl)[LB], int rbase) {
+        float amp[LB][2];
+        ksp_abs_c64_batch<LB>(raw, amp);
 #pragma unroll
         for (int u = 0; u < LB; u++) {
             const int row = rbase + r0 + u * RSTEP;
-            float a0 = ksp_abs_c64(raw[u].x, raw[u].y);
-            float a1 = ksp_abs_c64(raw[u].z, raw[u].w);
+            float a0 = amp[u][0], a1 = amp[u][1];
             if (MODE == KSP_FLAGS_CHANNEL) {
                 if (fl[u]) a0 = a1 = __builtin_nanf("");
             } else if (MODE == KSP_FLAGS_FULL) {

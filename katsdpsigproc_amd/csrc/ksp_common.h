@@ -68,6 +68,39 @@ __device__ __forceinline__ float ksp_abs_c64(float re, float im)
     return a;
 }
 
+// The same value for max(|re|, |im|) in [2^-63, 2^65) with the division written out:
+// the instruction sequence the compiler emits for an IEEE division (reciprocal, one
+// Newton step on it, quotient, two residual corrections) without the operand scaling
+// before it and the special-case fix-up after it, four half-rate instructions that do
+// nothing in this range -- v_div_scale leaves operands alone unless the denominator or
+// 1/denominator is subnormal or the quotient is below 2^-126 (numerator below 2^-103),
+// and a quotient that small only has to stay small: r < 2^-12 gives fma(r, r, 1) = 1
+// either way. No zero, infinity or NaN gets here, so the guards of the general form go
+// too. ksp_abs_in_range() says whether a sample qualifies: callers accumulate the keys
+// of a batch with AND and take this form when bit 30 survives in every lane.
+__device__ __forceinline__ unsigned ksp_abs_range_key(float re, float im)
+{
+    const unsigned ur = __float_as_uint(re) & 0x7fffffffu;
+    const unsigned ui = __float_as_uint(im) & 0x7fffffffu;
+    // exponent field e -> e + 64: bit 30 is set exactly for 64 <= e < 192
+    return max(ur, ui) + (64u << 23);
+}
+constexpr unsigned KSP_ABS_RANGE_BIT = 1u << 30;
+
+__device__ __forceinline__ float ksp_abs_c64_inrange(float re, float im)
+{
+    const unsigned ur = __float_as_uint(re) & 0x7fffffffu;
+    const unsigned ui = __float_as_uint(im) & 0x7fffffffu;
+    const float mx = __uint_as_float(max(ur, ui)), mn = __uint_as_float(min(ur, ui));
+    const float y0 = __builtin_amdgcn_rcpf(mx);
+    const float y = __fmaf_rn(__fmaf_rn(-mx, y0, 1.0f), y0, y0);
+    const float q0 = __fmul_rn(mn, y);
+    const float q1 = __fmaf_rn(__fmaf_rn(-mx, q0, mn), y, q0);
+    const float r = __fmaf_rn(__fmaf_rn(-mx, q1, mn), y, q1);
+    const float t = __fmaf_rn(r, r, 1.0f);  // in [1, 2]
+    return __fmul_rn(mx, ksp_sqrt_1_2(t));
+}
+
 // Wave-wide (64-lane) reductions with every lane receiving the result.
 // Wavefront vote as a scalar mask: v_cmp writes the lane mask straight into a scalar
 // register pair, so "any lane" is one scalar compare (HIP's __any/__ballot go through
@@ -77,6 +110,31 @@ __device__ __forceinline__ unsigned long long ksp_ballot(bool x)
     return __builtin_amdgcn_ballot_w64(x);
 }
 __device__ __forceinline__ bool ksp_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
+
+// |z| of the N pairs of visibilities a lane holds (v.x + j v.y, v.z + j v.w): the short
+// division when every magnitude of the batch, in every lane of the wavefront, is an
+// ordinary one, otherwise the general form for all of them.
+template <int N>
+__device__ __forceinline__ void ksp_abs_c64_batch(const float4 (&v)[N], float (&amp)[N][2])
+{
+    unsigned key = ~0u;
+#pragma unroll
+    for (int u = 0; u < N; u++)
+        key &= ksp_abs_range_key(v[u].x, v[u].y) & ksp_abs_range_key(v[u].z, v[u].w);
+    if (!ksp_any((key & KSP_ABS_RANGE_BIT) == 0)) {
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            amp[u][0] = ksp_abs_c64_inrange(v[u].x, v[u].y);
+            amp[u][1] = ksp_abs_c64_inrange(v[u].z, v[u].w);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            amp[u][0] = ksp_abs_c64(v[u].x, v[u].y);
+            amp[u][1] = ksp_abs_c64(v[u].z, v[u].w);
+        }
+    }
+}
 
 // Wavefront reductions on the DPP network (no LDS round trip, result wave-uniform):
 // four row shifts leave each row's total in its lane 15, row_bcast:15 / row_bcast:31

@@ -383,6 +383,33 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @pytest.mark.parametrize("channels", [4096, 8192])
+    def test_magnitude_range(self, channels, context, command_queue, oracle):
+        """The loaders take a shorter division for batches of ordinary magnitudes
+        (2^-63 <= max(|re|, |im|) < 2^65) and the general one otherwise: baselines scaled to
+        either side of both limits, and exact zeros, tiny and huge samples sprinkled over
+        ordinary data so that batches of either kind alternate inside a strip."""
+        rs = np.random.RandomState(61)
+        baselines = 24
+        vis = inputs.generate_data(channels, baselines, seed=62).astype(np.complex128)
+        for bl, scale in enumerate([2.0**-64, 2.0**-62, 2.0**-61, 2.0**62, 2.0**63, 2.0**64,
+                                    2.0**66, 2.0**-70, 2.0**-100, 2.0**100]):  # fmt: skip
+            vis[:, 4 + bl] *= scale
+        vis = vis.astype(np.complex64)
+        hit = rs.random_sample(vis.shape) < 0.002
+        hit[:, 4:14] = False
+        kind = rs.randint(0, 4, vis.shape)
+        vis[hit & (kind == 0)] = 0
+        vis[hit & (kind == 1)] *= np.float32(2.0**-90)
+        vis[hit & (kind == 2)] *= np.float32(2.0**80)
+        vis[hit & (kind == 3)] = np.complex64(complex(1.0, 2.0**-80))
+        out = run_fused(make_template(context), command_queue, vis, n_sigma=11.0)
+        with np.errstate(all="ignore"):
+            ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, want_deviations=True)
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
     @pytest.mark.parametrize("mode", ["none", "channel"])
     def test_degenerate_full_band(self, mode, context, command_queue, oracle):
         """4096 channels (bit-plane MAD, merging or sorted-window median): all-zero and

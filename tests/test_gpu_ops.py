@@ -664,6 +664,38 @@ class TestArithmetic:
         np.testing.assert_array_equal(np.sqrt(x), expected)  # numpy's float32 sqrt is IEEE too
         np.testing.assert_array_equal(out, expected)
 
+    def test_abs_short_division(self):
+        """Magnitudes in [2^-63, 2^65) take the division without scaling and fix-up
+        (ksp_abs_c64_inrange): 2^24 pairs per round with the larger part over that whole
+        range, edges included, ratios from 2^-30 to 1 and mantissas at the extremes."""
+        rs = np.random.RandomState(99)
+        n = 1 << 24
+        for round_ in range(3):
+            e_big = rs.randint(-63, 65, n).astype(np.float64)
+            if round_ == 1:
+                e_big[:] = rs.choice([-63.0, 64.0, 0.0], n)
+            m_big = 1.0 + rs.random_sample(n)
+            ratio = np.exp2(-rs.uniform(0, 30 if round_ < 2 else 1.5, n))
+            mx = (np.exp2(e_big) * m_big).astype(np.float32)
+            mn = (mx.astype(np.float64) * ratio).astype(np.float32)
+            # mantissa extremes for a share of the samples
+            edge = rs.randint(0, 8, n)
+            mxb, mnb = mx.view(np.uint32), mn.view(np.uint32)
+            mxb[edge == 0] |= np.uint32(0x7FFFFF)
+            mxb[edge == 1] &= np.uint32(0xFF800000)
+            mnb[edge == 2] |= np.uint32(0x7FFFFF)
+            mnb[edge == 3] &= np.uint32(0xFF800000)
+            mn = np.minimum(mn, mx)
+            swap = rs.random_sample(n) < 0.5
+            sign_r = np.where(rs.random_sample(n) < 0.5, -1, 1).astype(np.float32)
+            sign_i = np.where(rs.random_sample(n) < 0.5, -1, 1).astype(np.float32)
+            re = np.where(swap, mn, mx) * sign_r
+            im = np.where(swap, mx, mn) * sign_i
+            out = self._run("ksp_selftest_abs", n, re, im)
+            z = np.empty(n, np.complex64)
+            z.real, z.imag = re, im
+            np.testing.assert_array_equal(out, np.abs(z))
+
     def test_abs_matches_numpy(self, oracle):
         """|z| is numpy's complex64 abs bit for bit: random magnitudes over the whole
         exponent range, equal parts, zeros, denormals, infinities and NaNs."""

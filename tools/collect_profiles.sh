@@ -12,8 +12,13 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.log 2>&1
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+# the default command as the driver runs it (adds the RFI-laden variant and the bring-up
+# shapes of configs 2 and 3: their kernels' durations; the fused kernel's average mixes shapes)
+rm -rf /tmp/ktd
+rocprofv3 --kernel-trace --stats -d /tmp/ktd -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_default_under_rocprof.log 2>&1
+cp $(find /tmp/ktd -name "*kernel_stats.csv" | head -1) $OUT/bench_default_kernel_stats.csv
 for MODE in NONE CHANNEL; do
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do

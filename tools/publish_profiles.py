@@ -13,7 +13,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, ver = sys.argv[1], sys.argv[2]
 src = os.path.join(root, "gpurun_out", f"profiles_{tag}")
 rnd = tag[:3]
-for name in ("bench_kernel_stats.csv", "kernel_stats_NONE.csv", "kernel_stats_CHANNEL.csv"):
+for name in ("bench_kernel_stats.csv", "bench_default_kernel_stats.csv", "kernel_stats_NONE.csv",
+             "kernel_stats_CHANNEL.csv"):
     shutil.copy(os.path.join(src, name),
                 os.path.join(root, "profiles", f"{rnd}_{name[:-4]}_{ver}.csv"))
 shutil.copy(os.path.join(src, "pmc_summary.json"),

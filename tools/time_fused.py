@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: time the fused flagger kernel of one library build on the benchmark shape.
 
-    usage: tools/time_fused.py [path/to/lib.so] [NONE|CHANNEL|FULL] [rfi] [dev]
+    usage: tools/time_fused.py [path/to/lib.so] [NONE|CHANNEL|FULL] [rfi] [dev] [each]
 
 Prints the kernel's mean / min duration (HIP events around the kernel itself) and the
 device time per step (zero-fill + kernel). Input: tiled standard-normal block (cheap to
@@ -49,7 +49,9 @@ if mode == "CHANNEL":
     fn.buffer("input_flags").set(q, (np.random.RandomState(2).random_sample(channels) < 1 / 16).astype(np.uint8))
 elif mode == "FULL":
     fn.buffer("input_flags").set(q, (rs.random_sample((channels, baselines)) < 1 / 16).astype(np.uint8))
-for _ in range(3):
+# (the device reaches its sustained clocks only after some tens of milliseconds of load:
+# launches right after an idle period take up to 15 % longer)
+for _ in range(int(os.environ.get("W", 60))):
     fn()
 q.finish()
 marks = [q.enqueue_marker()]
@@ -67,3 +69,5 @@ flagged = np.count_nonzero(fn.buffer("flags").get(q)) / (channels * baselines)
 print(f"{os.path.basename(lib) if lib else 'product':28s} {mode:7s} {'rfi' if 'rfi' in args else 'clean':5s} "
       f"kernel mean {np.mean(k):.4f} min {np.min(k):.4f} max {np.max(k):.4f} ms; step {np.mean(s):.4f} ms; "
       f"flagged {flagged:.4f}", flush=True)
+if "each" in args:  # the individual launches, in order (drift or scatter?)
+    print(" ".join(f"{x:.3f}" for x in k))
