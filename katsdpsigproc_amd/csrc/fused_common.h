@@ -571,13 +571,15 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     //    and the zeros can be counted from the bit planes below instead of with a
     //    compare per sample. float32(|d|) is monotone in |d| and so is this rounding,
     //    hence the key bin of the median can be found without knowing any exact value.
-    //    (Patterns above 0x7fff0000 -- NaN deviations only -- saturate at 0x7fff.)
+    //    A deviation is finite or the default NaN (of inf - inf): |pattern| <= 0x7fc00000,
+    //    so the addition carries neither into the sign bit nor past it -- it is done on
+    //    the signed pattern and the two sign bits are cleared after packing.
     unsigned kp[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        const unsigned a = min((__float_as_uint(dev[2 * i]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu);
-        const unsigned b = min((__float_as_uint(dev[2 * i + 1]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu);
-        kp[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // bytes 2,3 of each, side by side
+        const unsigned a = __float_as_uint(dev[2 * i]) + 0xffffu;
+        const unsigned b = __float_as_uint(dev[2 * i + 1]) + 0xffffu;
+        kp[i] = __builtin_amdgcn_perm(b, a, 0x07060302u) & 0x7fff7fffu;  // bytes 2,3 of each
     }
     int zeros;
     if constexpr (R != 64) zeros = count_less16<NP>(kp, 1);
@@ -1012,9 +1014,11 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
         const int w = 1 << k;
         const float thrf = thr[k];
         const double limit = (double)__fmul_rn(thrf, (float)w);  // host.py:242
+        if (ksp_any(fl != 0)) {  // (nothing flagged so far in this wavefront: nothing to replace)
 #pragma unroll
-        for (int j = 0; j < R; j++)
-            if ((fl >> j) & 1) d[j] = thrf;  // host.py:237 (exact: thr is a float32)
+            for (int j = 0; j < R; j++)
+                if ((fl >> j) & 1) d[j] = thrf;  // host.py:237 (exact: thr is a float32)
+        }
         // the next lanes' first 7 values and flag bits (w - 1 <= 7 are used)
         float ext[7];
 #pragma unroll

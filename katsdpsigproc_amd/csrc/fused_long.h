@@ -181,9 +181,10 @@ __device__ __forceinline__ double mad_noise_long(const float (&dev)[NR][64], int
     for (int g = 0; g < NR; g++) {
 #pragma unroll
         for (int i = 0; i < 32; i++) {
-            const unsigned a = min((__float_as_uint(dev[g][2 * i]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu);
-            const unsigned b = min((__float_as_uint(dev[g][2 * i + 1]) & 0x7fffffffu) + 0xffffu, 0x7fffffffu);
-            np[g][i] = __builtin_amdgcn_perm(b, a, 0x07060302u) ^ 0x7fff7fffu;
+            // (signed patterns: see mad_noise in fused_common.h)
+            const unsigned a = __float_as_uint(dev[g][2 * i]) + 0xffffu;
+            const unsigned b = __float_as_uint(dev[g][2 * i + 1]) + 0xffffu;
+            np[g][i] = ~__builtin_amdgcn_perm(b, a, 0x07060302u) & 0x7fff7fffu;
         }
         transpose_bits32(np[g]);
     }
