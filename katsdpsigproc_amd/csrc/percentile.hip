@@ -66,26 +66,57 @@ template <bool IS_AMP>
 __global__ __launch_bounds__(256) void percentile5_wave_kernel(const void *__restrict__ in,
                                                                float *__restrict__ out, int rows,
                                                                int in_stride, int out_stride,
-                                                               int first_col, int n_cols)
+                                                               int first_col, int n_cols,
+                                                               int vec_ok)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;  // whole wavefronts leave together
+    // lane l holds columns [64 l, 64 l + 64): 256 (512) contiguous bytes per lane, read
+    // with 16-byte loads when the row allows it (measured faster than the same bytes
+    // interleaved over the lanes, and much faster than 4-byte loads)
     const size_t base = (size_t)row * in_stride + first_col + lane * 64;
+    float amp[64];
+    const bool full = lane * 64 + 64 <= n_cols;
+    if (vec_ok && full) {
+        if (IS_AMP) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float4 q = *(const float4 *)((const float *)in + base + 4 * i);
+                amp[4 * i] = q.x;
+                amp[4 * i + 1] = q.y;
+                amp[4 * i + 2] = q.z;
+                amp[4 * i + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const float4 q = *(const float4 *)((const float2 *)in + base + 2 * i);
+                amp[2 * i] = ksp_abs_c64(q.x, q.y);
+                amp[2 * i + 1] = ksp_abs_c64(q.z, q.w);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            amp[i] = 0.0f;
+            if (lane * 64 + i < n_cols) {
+                if (IS_AMP)
+                    amp[i] = ((const float *)in)[base + i];
+                else {
+                    const float2 z = ((const float2 *)in)[base + i];
+                    amp[i] = ksp_abs_c64(z.x, z.y);
+                }
+            }
+        }
+    }
     unsigned key[64];
     unsigned kmin = 0xffffffffu, kmax = 0;
 #pragma unroll
     for (int i = 0; i < 64; i++) {
         unsigned k = 0xffffffffu;  // columns beyond the range: above every real key
-        if (lane * 64 + i < n_cols) {
-            float a;
-            if (IS_AMP)
-                a = ((const float *)in)[base + i];
-            else {
-                const float2 z = ((const float2 *)in)[base + i];
-                a = ksp_abs_c64(z.x, z.y);
-            }
-            const unsigned u = __float_as_uint(a);
+        if (full || lane * 64 + i < n_cols) {
+            const unsigned u = __float_as_uint(amp[i]);
             k = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
             kmin = min(kmin, k);
             kmax = max(kmax, k);
@@ -152,8 +183,11 @@ static int launch_percentile(hipStream_t s, const void *in, float *out, int rows
                              int out_stride, int first_col, int n_cols)
 {
     if (n_cols > 1024 && n_cols <= 4096) {
+        // 16-byte loads: every lane's first element 16-byte aligned
+        const int per16 = IS_AMP ? 4 : 2;
+        const int vec_ok = (in_stride % per16 == 0) && (first_col % per16 == 0) && ((uintptr_t)in % 16 == 0);
         hipLaunchKernelGGL((percentile5_wave_kernel<IS_AMP>), dim3(ksp_divup(rows, 4)), dim3(256), 0, s,
-                           in, out, rows, in_stride, out_stride, first_col, n_cols);
+                           in, out, rows, in_stride, out_stride, first_col, n_cols, vec_ok);
         KSP_LAUNCH_CHECK();
         return 0;
     }

@@ -27,8 +27,9 @@ for MODE in NONE CHANNEL; do
     FLAGS=$MODE N=3 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm_$i -o p --output-format csv -- python3 $R/tools/run_fused.py > /tmp/pm_$i.log 2>&1
     cp $(find /tmp/pm_$i -name "*counter_collection.csv" | head -1) $OUT/pmc_${MODE}_pass$i.csv
   done
+  # (300 launches: the first ~40 after idle run at rising clocks, see bench.py)
   rm -rf /tmp/kt_$MODE
-  FLAGS=$MODE N=12 rocprofv3 --kernel-trace --stats -d /tmp/kt_$MODE -o k --output-format csv -- python3 $R/tools/run_fused.py > /tmp/kt_$MODE.log 2>&1
+  FLAGS=$MODE N=300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$MODE -o k --output-format csv -- python3 $R/tools/run_fused.py > /tmp/kt_$MODE.log 2>&1
   cp $(find /tmp/kt_$MODE -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$MODE.csv
 done
 python3 - $OUT <<'PY'

@@ -3,12 +3,15 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from katsdpsigproc_amd import _lib
+if os.environ.get('KSP_LIB'): _lib.load(os.path.abspath(os.environ['KSP_LIB']))
 from katsdpsigproc_amd import accel, percentile
 from katsdpsigproc_amd.rfi import device
 ctx = accel.create_some_context(False); q = ctx.create_command_queue()
 rs = np.random.RandomState(1)
-def timeit(fn, reps=20):
-    fn(); q.finish(); a = q.enqueue_marker()
+def timeit(fn, reps=200):
+    for _ in range(100): fn()
+    q.finish(); a = q.enqueue_marker()
     for _ in range(reps): fn()
     b = q.enqueue_marker(); q.finish(); return b.time_since(a) / reps
 n = 4096
