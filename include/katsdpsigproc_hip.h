@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KSP_ABI_VERSION 2
+#define KSP_ABI_VERSION 3
 
 /* BackgroundFlags (reference: rfi/device.py:40-46) */
 #define KSP_FLAGS_NONE 0
@@ -75,6 +75,10 @@ int ksp_stream_create(int device, void **stream);
 int ksp_stream_destroy(int device, void *stream);
 int ksp_stream_synchronize(int device, void *stream);
 int ksp_event_create(int device, void **event);
+/* An event that only orders work between streams of this device: no time stamp and no
+ * system-scope fence (cache write-back + invalidate) when it is recorded. Not for
+ * ksp_event_elapsed_ms, and not for handing results to the host. */
+int ksp_event_create_ordering(int device, void **event);
 int ksp_event_destroy(int device, void *event);
 int ksp_event_record(int device, void *event, void *stream);
 int ksp_event_synchronize(int device, void *event);

@@ -14,7 +14,7 @@ from ctypes import c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_native", "libkatsdpsigproc_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -50,6 +50,7 @@ SIGNATURES = {
     "ksp_stream_destroy": [c_int, c_void_p],
     "ksp_stream_synchronize": [c_int, c_void_p],
     "ksp_event_create": [c_int, POINTER(c_void_p)],
+    "ksp_event_create_ordering": [c_int, POINTER(c_void_p)],
     "ksp_event_destroy": [c_int, c_void_p],
     "ksp_event_record": [c_int, c_void_p, c_void_p],
     "ksp_event_synchronize": [c_int, c_void_p],

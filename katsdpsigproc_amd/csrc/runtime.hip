@@ -119,6 +119,16 @@ int ksp_event_create(int device, void **event)
     return 0;
 }
 
+int ksp_event_create_ordering(int device, void **event)
+{
+    KSP_REQUIRE(event != nullptr, "event is NULL");
+    KSP_CHECK(hipSetDevice(device));
+    hipEvent_t e;
+    KSP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    *event = (void *)e;
+    return 0;
+}
+
 int ksp_event_destroy(int device, void *event)
 {
     KSP_CHECK(hipSetDevice(device));

@@ -494,9 +494,14 @@ class CommandQueue(AbstractCommandQueue):
                   (ctypes.c_uint * 3)(*grid), (ctypes.c_uint * 3)(*block), 0, params)  # fmt: skip
 
     # -- synchronisation
-    def enqueue_marker(self) -> Event:
+    def enqueue_marker(self, ordering_only: bool = False) -> Event:
+        """Record an event behind the work enqueued so far. ``ordering_only`` events serve
+        ``enqueue_wait_for_events`` of other queues of this device and nothing else (no
+        ``time_since``, no hand-over to the host): recording them costs the stream no
+        cache write-back."""
         handle = ctypes.c_void_p()
-        _lib.call("ksp_event_create", self._dev, ctypes.byref(handle))
+        _lib.call("ksp_event_create_ordering" if ordering_only else "ksp_event_create",
+                  self._dev, ctypes.byref(handle))  # fmt: skip
         event = Event(self._dev, handle.value)
         _lib.call("ksp_event_record", self._dev, ctypes.c_void_p(event.handle), self._s)
         return event

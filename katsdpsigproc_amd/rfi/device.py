@@ -996,6 +996,7 @@ class FusedFlaggerDevice(accel.Operation):
         # caller could usefully bind)
         self._workspace = accel.DeviceArray(command_queue.context, (16,), np.uint32)
         self._workspace.zero(command_queue)
+        self._armed = None
 
     def _run(self) -> None:
         bg = self.template.background
@@ -1029,6 +1030,7 @@ class FusedFlaggerDevice(accel.Operation):
                 self._workspace.buffer,
             ],
         )
+        self._armed = None  # (events of profile_next_run are recorded now: ours to drop)
 
     def profile_next_run(self):
         """Arm two events around the flagger kernel of the next call (excluding the
@@ -1040,6 +1042,7 @@ class FusedFlaggerDevice(accel.Operation):
         start, stop = queue.create_event(), queue.create_event()
         _lib.call("ksp_flagger_fused_profile", ctypes.c_void_p(start.handle),
                   ctypes.c_void_p(stop.handle))  # fmt: skip
+        self._armed = (start, stop)  # alive until the call, whatever the caller does with them
         return start, stop
 
     def parameters(self) -> Mapping[str, Any]:

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_abi_version_and_no_device_calls(lib):
     from katsdpsigproc_amd import _lib
 
-    assert lib.ksp_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.ksp_abi_version() == _lib.ABI_VERSION == 3
     count = ctypes.c_int(-1)
     assert lib.ksp_device_count(ctypes.byref(count)) == 0
     assert count.value >= 0  # 0 in the CPU container
