@@ -793,17 +793,28 @@ class FlaggerDeviceTemplate:
         bytes per sample of HBM traffic). Off by default: in the reference ``deviations``
         is a *temporary* slot of the flagger (reference rfi/device.py:1081-1091), which a
         single-pass kernel has no need to materialise. The sequence always has it.
+    tuning
+        Fused path only: ``{"vis_pad": n}``, the number of elements by which the rows of the
+        ``vis`` slot are padded beyond `baselines` (the kernel reads 32-byte pieces of 4096
+        rows at a time, and how fast the memory system serves that depends on the row
+        stride: at 32768 baselines 2 % faster with 512, 18 % slower with 256). By default
+        it is autotuned per shape when the operation is instantiated.
     """
+
+    autotune_version = 1
+    _VIS_PADS = (0, 16, 32, 512, 2048)
 
     def __init__(self, background: AbstractBackgroundDeviceTemplate,
                  noise_est: AbstractNoiseEstDeviceTemplate,
                  threshold: AbstractThresholdDeviceTemplate,
-                 fused: Optional[bool] = None, keep_deviations: bool = False) -> None:  # fmt: skip
+                 fused: Optional[bool] = None, keep_deviations: bool = False,
+                 tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
         self.background = background
         self.noise_est = noise_est
         self.threshold = threshold
         self.fused = fused
         self.keep_deviations = keep_deviations
+        self._fused_tuning = dict(tuning) if tuning is not None else None
         context = background.context
         assert noise_est.context is context
         assert threshold.context is context
@@ -842,6 +853,51 @@ class FlaggerDeviceTemplate:
             return False
         return bool(_lib.call("ksp_flagger_fused_supported", channels, bg.width, n_windows))
 
+    @classmethod
+    @tune.autotuner(test={"vis_pad": 0})
+    def autotune(cls, context: AbstractContext, channels: int, baselines: int, width: int,
+                 is_amplitude: bool, use_flags: BackgroundFlags, sum_threshold: bool,
+                 n_windows: int) -> Mapping[str, Any]:  # fmt: skip
+        """Row padding of ``vis`` for the fused kernel at exactly this shape: the candidates
+        are timed on standard-normal data (no interference, 11 sigma)."""
+        if baselines < 2048:
+            return {"vis_pad": 0}  # a handful of workgroups per CU: nothing to tune
+        queue = context.create_tuning_command_queue()
+        rs = np.random.RandomState(seed=1)
+        tile = min(baselines, 1024)
+        if is_amplitude:
+            block = np.abs(rs.standard_normal((channels, tile))).astype(np.float32)
+        else:
+            block = rs.standard_normal((channels, tile, 2)).astype(np.float32).view(np.complex64)[..., 0]
+        data = np.tile(block, (1, -(-baselines // tile)))[:, :baselines]
+        if use_flags == BackgroundFlags.CHANNEL:
+            mask = (rs.random_sample(channels) < 1 / 16).astype(np.uint8)
+        elif use_flags == BackgroundFlags.FULL:
+            mask = (rs.random_sample((channels, baselines)) < 1 / 16).astype(np.uint8)
+        bg = BackgroundMedianFilterDeviceTemplate(context, width, is_amplitude, use_flags,
+                                                  tuning={"wgs": 64, "csplit": 0})  # fmt: skip
+        ne = NoiseEstMADTDeviceTemplate(context, max(channels, 1), tuning={"wgsx": 256})
+        if sum_threshold:
+            th: AbstractThresholdDeviceTemplate = ThresholdSumDeviceTemplate(
+                context, n_windows, tuning={"wgsx": 256, "vt": 0})  # fmt: skip
+        else:
+            th = ThresholdSimpleDeviceTemplate(context, False, tuning={"wgsx": 64, "wgsy": 4})
+
+        def generate(vis_pad: int):
+            template = cls(bg, ne, th, fused=True, tuning={"vis_pad": vis_pad})
+            op = template.instantiate(queue, channels, baselines, threshold_args={"n_sigma": 11.0})
+            op.ensure_all_bound()
+            op.buffer("vis").set(queue, data)
+            if use_flags != BackgroundFlags.NONE:
+                op.buffer("input_flags").set(queue, mask)
+            for _ in range(60):  # every candidate starts at sustained clocks
+                op()
+            queue.finish()
+            return tune.make_measure(queue, op)
+
+        best = tune.autotune(generate, threads=1, vis_pad=list(cls._VIS_PADS))
+        return {"vis_pad": int(best["vis_pad"])}
+
     def instantiate(self, command_queue: AbstractCommandQueue, channels: int, baselines: int,
                     background_args: Mapping[str, Any] = {},
                     noise_est_args: Mapping[str, Any] = {},
@@ -856,8 +912,17 @@ class FlaggerDeviceTemplate:
         elif use_fused and not self.fusable(channels):
             raise ValueError("this combination of stages/shape cannot use the fused kernel")
         if use_fused:
+            if self._fused_tuning is not None:
+                vis_pad = int(self._fused_tuning.get("vis_pad", 0))
+            else:
+                th = self.threshold
+                vis_pad = int(self.autotune(
+                    self.context, channels, baselines, self.background.width,
+                    self.background.is_amplitude, self.background.use_flags,
+                    isinstance(th, ThresholdSumDeviceTemplate), getattr(th, "n_windows", 1),
+                )["vis_pad"])  # fmt: skip
             return FusedFlaggerDevice(
-                self, command_queue, channels, baselines, threshold_args, allocator
+                self, command_queue, channels, baselines, threshold_args, allocator, vis_pad
             )
         return FlaggerDevice(
             self, command_queue, channels, baselines, background_args, noise_est_args,
@@ -954,8 +1019,10 @@ class FusedFlaggerDevice(accel.Operation):
 
     def __init__(self, template: FlaggerDeviceTemplate, command_queue: AbstractCommandQueue,
                  channels: int, baselines: int, threshold_args: Mapping[str, Any] = {},
-                 allocator: Optional[AbstractAllocator] = None) -> None:  # fmt: skip
+                 allocator: Optional[AbstractAllocator] = None, vis_pad: int = 0) -> None:  # fmt: skip
         super().__init__(command_queue, allocator)
+        if vis_pad < 0 or vis_pad % 2:
+            raise ValueError("vis_pad must be even and not negative")
         self.template = template
         self.kernel = template._fused_kernel
         self.channels = channels
@@ -978,9 +1045,12 @@ class FusedFlaggerDevice(accel.Operation):
         if args:
             raise TypeError(f"unexpected threshold arguments {sorted(args)}")
         vis_type = np.float32 if bg.is_amplitude else np.complex64
-        # 16-byte loads of baseline pairs want an even row stride
+        # 16-byte loads of baseline pairs want an even row stride; `vis_pad` more elements
+        # per row where that stride suits the memory system better (template's `tuning`)
+        self.vis_pad = vis_pad
         self.slots["vis"] = accel.IOSlot(
-            (channels, accel.Dimension(baselines, alignment=2)), vis_type
+            (channels, accel.Dimension(baselines, min_padded_size=baselines + vis_pad, alignment=2)),
+            vis_type,
         )
         if bg.use_flags == BackgroundFlags.FULL:
             self.slots["input_flags"] = accel.IOSlot((channels, accel.Dimension(baselines)), np.uint8)
@@ -1048,6 +1118,7 @@ class FusedFlaggerDevice(accel.Operation):
     def parameters(self) -> Mapping[str, Any]:
         return {
             "fused": True,
+            "vis_pad": self.vis_pad,
             "keep_deviations": "deviations" in self.slots,
             "width": self.template.background.width,
             "n_sigma": self.n_sigma,

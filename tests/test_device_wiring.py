@@ -156,6 +156,16 @@ def test_fused_selection_and_slots(context, queue):
         queue, 1024, 16, threshold_args={"n_sigma": 11.0, "threshold_falloff": 1.5})
     assert set(lean.slots) == {"vis", "input_flags", "noise", "flags"}
     assert list(lean.scales) == [1.5**-i for i in range(4)]
+    # row padding of vis: from the template's tuning, into the slot's requirement and the stride
+    padded = templates(context, tuning={"vis_pad": 32}).instantiate(
+        queue, 4096, 64, threshold_args={"n_sigma": 11.0})
+    assert padded.slots["vis"].dimensions[1].required_padded_size() == 96
+    assert padded.parameters()["vis_pad"] == 32
+    padded.ensure_all_bound()
+    padded()
+    assert int(queue.launches[-1][1][7]) == 96  # vis_stride
+    with pytest.raises(ValueError):
+        templates(context, tuning={"vis_pad": 3}).instantiate(queue, 64, 8, threshold_args={"n_sigma": 1})
     # falls back to the sequence when the fused kernel cannot do it
     assert isinstance(templates(context, noise_t=False).instantiate(queue, 16384, 8, threshold_args={"n_sigma": 1}),
                       device.FlaggerDevice)  # fmt: skip

@@ -383,6 +383,53 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @pytest.mark.parametrize("channels, baselines, vis_pad, mode", [
+        (4096, 50, 32, "none"), (4096, 33, 512, "full"), (1000, 21, 16, "channel"),
+        (8192, 10, 32, "none"), (512, 7, 2048, "none"),
+    ])  # fmt: skip
+    def test_padded_rows(self, channels, baselines, vis_pad, mode, context, command_queue, oracle):
+        """``tuning={"vis_pad": n}``: rows of `vis` padded beyond the baselines (the stride
+        the autotuner picks for large blocks) change nothing in the results."""
+        from katsdpsigproc_amd.rfi import device
+
+        rs = np.random.RandomState(5)
+        vis = inputs.add_rfi(inputs.generate_data(channels, baselines, seed=71), seed=72)
+        fl = None
+        if mode == "channel":
+            fl = inputs.channel_mask(channels)
+        elif mode == "full":
+            fl = (rs.random_sample(vis.shape) < 0.1).astype(np.uint8)
+        template = make_template(context, mode.upper(), tuning={"vis_pad": vis_pad})
+        fn = template.instantiate(command_queue, channels, baselines, threshold_args={"n_sigma": 9.0})
+        assert fn.slots["vis"].dimensions[1].required_padded_size() >= baselines + vis_pad
+        out = run_fused(template, command_queue, vis, fl, n_sigma=9.0)
+        ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, fl, n_sigma=9.0, want_deviations=True)
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
+    @pytest.mark.force_autotune
+    def test_autotune_vis_pad(self, context, command_queue, oracle):
+        """The search over row paddings runs at the instantiated shape and returns one of
+        its candidates; results with the chosen padding match the oracle."""
+        from katsdpsigproc_amd.rfi import device
+
+        channels, baselines = 4096, 2048
+        template = make_template(context)  # no tuning given: autotuned at instantiation
+        fn = template.instantiate(command_queue, channels, baselines, threshold_args={"n_sigma": 11.0})
+        assert fn.vis_pad in device.FlaggerDeviceTemplate._VIS_PADS
+        vis = inputs.add_rfi(inputs.generate_data(channels, baselines, seed=73), seed=74)
+        oracle.set_threads(16)
+        try:
+            ref_flags, ref_noise = oracle.flagger_full(vis, n_sigma=11.0)
+        finally:
+            oracle.set_threads(1)
+        fn.ensure_all_bound()
+        fn.buffer("vis").set(command_queue, vis)
+        fn()
+        np.testing.assert_array_equal(ref_flags, fn.buffer("flags").get(command_queue))
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), fn.buffer("noise").get(command_queue))
+
     @pytest.mark.parametrize("channels", [4096, 8192])
     def test_magnitude_range(self, channels, context, command_queue, oracle):
         """The loaders take a shorter division for batches of ordinary magnitudes
