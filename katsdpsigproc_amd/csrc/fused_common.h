@@ -539,10 +539,21 @@ __device__ __forceinline__ void rank_lanes64(double x, int n, int r, int lane, d
                                              double &prev, bool &have_prev)
 {
     const bool live = lane < n;
+    // Unrolled in blocks of 8 with a wave-uniform exit: with the lane numbers constants,
+    // a broadcast is two v_readlane with immediate lane selects and the tie-break a
+    // constant lane mask (a loop over a run-time lane number stalls on every select:
+    // 190 cycles per candidate, measured). Idle lanes hold NaN, which never counts.
+    const double xs = live ? x : __builtin_nan("");
     int cnt = 0;
-    for (int jj = 0; jj < n; jj++) {
-        const double y = ksp_bcast(x, jj);
-        cnt += (y < x) || (y == x && jj < lane);
+#pragma unroll
+    for (int blk = 0; blk < 64; blk += 8) {
+        if (blk >= n) break;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int jj = blk + u;
+            const double y = ksp_bcast(xs, jj);
+            cnt += (y < xs) || (y == xs && jj < lane);
+        }
     }
     xk = ksp_bcast(x, __ffsll((long long)ksp_ballot(live && cnt == r)) - 1);
     have_prev = r >= 1;
@@ -896,6 +907,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             prev = ksp_wave_max(m);
         }
     }
+    stamp(14);
     if (even) xk = (xk + prev) / 2.0;  // float64 mean, as numpy.median
     return xk * FUSED_MAD_NORMAL;
 }

@@ -28,6 +28,11 @@ if a16[:, 12:14].any():
     m = a16[okm].astype(np.int64)
     print("rank+exact split: exact_dev %.0f, rank %.0f, rest of MAD %.0f" % (
         (m[:, 12] - m[:, 11]).mean(), (m[:, 13] - m[:, 12]).mean(), (m[:, 4] - m[:, 13]).mean()))
+if a16[:, 14].any():
+    okm = ok & (a16[:, 13] > 0) & (a16[:, 14] > 0)
+    m = a16[okm].astype(np.int64)
+    print("after the ranking: to the end of mad_noise %.0f, from there to the MAD stamp of the kernel %.0f" % (
+        (m[:, 14] - m[:, 13]).mean(), (m[:, 4] - m[:, 14]).mean()))
 print("wave lifetime mean", (t[:, 6] - t[:, 0]).mean())
 # per CU: fraction of time in which k waves are in the load phase
 hwid = (hw & 0xffffffff).astype(np.int64)
