@@ -37,6 +37,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
+# The three-run long-band kernel repeats the median and threshold phases once per run of a
+# lane; at the default limit the compiler gives up unrolling those loops, the run number
+# becomes a run-time index and the 192 deviations of a lane move to scratch memory.
+PER_SOURCE_FLAGS = {
+    "flagger_fused_long3.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+}
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -71,7 +79,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         # (every source is a dependency of every object: one translation unit includes
         # another's .hip file)
         if force or _stale(obj, sources + headers):
-            jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
+            own = PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+            jobs.append([hipcc] + FLAGS + own + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
