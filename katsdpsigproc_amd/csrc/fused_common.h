@@ -244,7 +244,7 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
                 amp[u][1] = raw[u].z;
             }
         } else {
-            ksp_abs_c64_batch<LB>(raw, amp);
+            ksp_abs_c64_batch<LB, MODE == KSP_FLAGS_NONE>(raw, amp);
         }
 #pragma unroll
         for (int u = 0; u < LB; u++) {

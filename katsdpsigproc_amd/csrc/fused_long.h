@@ -116,7 +116,7 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
     };
     auto finish = [&](const float4 (&raw)[LB], const unsigned (&fl)[LB], int rbase) {
         float amp[LB][2];
-        ksp_abs_c64_batch<LB>(raw, amp);
+        ksp_abs_c64_batch<LB, MODE == KSP_FLAGS_NONE>(raw, amp);
 #pragma unroll
         for (int u = 0; u < LB; u++) {
             const int row = rbase + r0 + u * RSTEP;

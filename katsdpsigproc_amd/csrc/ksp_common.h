@@ -111,10 +111,42 @@ __device__ __forceinline__ unsigned long long ksp_ballot(bool x)
 }
 __device__ __forceinline__ bool ksp_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
 
+// Two of them at once with packed float32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two IEEE
+// operations per lane and instruction, same results): everything but the two reciprocals,
+// the two reciprocal square roots and the integer min/max is shared by the pair.
+typedef float ksp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ksp_abs_c64_inrange_x2(float re0, float im0, float re1, float im1,
+                                                       float &a0, float &a1)
+{
+    const unsigned ur0 = __float_as_uint(re0) & 0x7fffffffu, ui0 = __float_as_uint(im0) & 0x7fffffffu;
+    const unsigned ur1 = __float_as_uint(re1) & 0x7fffffffu, ui1 = __float_as_uint(im1) & 0x7fffffffu;
+    const ksp_f32x2 mx = {__uint_as_float(max(ur0, ui0)), __uint_as_float(max(ur1, ui1))};
+    const ksp_f32x2 mn = {__uint_as_float(min(ur0, ui0)), __uint_as_float(min(ur1, ui1))};
+    const ksp_f32x2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+    const ksp_f32x2 y0 = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    const ksp_f32x2 y = __builtin_elementwise_fma(__builtin_elementwise_fma(-mx, y0, one), y0, y0);
+    const ksp_f32x2 q0 = mn * y;
+    const ksp_f32x2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-mx, q0, mn), y, q0);
+    const ksp_f32x2 r = __builtin_elementwise_fma(__builtin_elementwise_fma(-mx, q1, mn), y, q1);
+    const ksp_f32x2 t = __builtin_elementwise_fma(r, r, one);  // in [1, 2]
+    // (ksp_sqrt_1_2 on both)
+    const ksp_f32x2 q = {__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y)};
+    const ksp_f32x2 g = t * q;
+    const ksp_f32x2 h = half * q;
+    const ksp_f32x2 e = __builtin_elementwise_fma(-g, g, t);
+    const ksp_f32x2 sq = __builtin_elementwise_fma(h, e, g);
+    const ksp_f32x2 a = mx * sq;
+    a0 = a.x;
+    a1 = a.y;
+}
+
 // |z| of the N pairs of visibilities a lane holds (v.x + j v.y, v.z + j v.w): the short
 // division when every magnitude of the batch, in every lane of the wavefront, is an
 // ordinary one, otherwise the general form for all of them.
-template <int N>
+// PACKED selects the two-at-once form of the short division (measured 3.6 % faster for the
+// kernel without input flags, 1 % slower when the other wavefront of the SIMD runs the
+// sorted-window median, i.e. with input flags).
+template <int N, bool PACKED = true>
 __device__ __forceinline__ void ksp_abs_c64_batch(const float4 (&v)[N], float (&amp)[N][2])
 {
     unsigned key = ~0u;
@@ -124,8 +156,12 @@ __device__ __forceinline__ void ksp_abs_c64_batch(const float4 (&v)[N], float (&
     if (!ksp_any((key & KSP_ABS_RANGE_BIT) == 0)) {
 #pragma unroll
         for (int u = 0; u < N; u++) {
-            amp[u][0] = ksp_abs_c64_inrange(v[u].x, v[u].y);
-            amp[u][1] = ksp_abs_c64_inrange(v[u].z, v[u].w);
+            if constexpr (PACKED) {
+                ksp_abs_c64_inrange_x2(v[u].x, v[u].y, v[u].z, v[u].w, amp[u][0], amp[u][1]);
+            } else {
+                amp[u][0] = ksp_abs_c64_inrange(v[u].x, v[u].y);
+                amp[u][1] = ksp_abs_c64_inrange(v[u].z, v[u].w);
+            }
         }
     } else {
 #pragma unroll

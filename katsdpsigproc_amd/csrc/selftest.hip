@@ -11,12 +11,20 @@ __global__ void selftest_sqrt12_kernel(float *out, int n)
 
 __global__ void selftest_abs_kernel(const float *re, const float *im, float *out, int n)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    // the form the loaders pick per batch, here per element: every sample that
-    // qualifies for the short division goes through it
-    if (i < n)
-        out[i] = (ksp_abs_range_key(re[i], im[i]) & KSP_ABS_RANGE_BIT) ? ksp_abs_c64_inrange(re[i], im[i])
-                                                                     : ksp_abs_c64(re[i], im[i]);
+    // the forms the loaders pick per batch, here per pair of elements: two samples that both
+    // qualify for the short division go through its packed form, a single one through the
+    // scalar form, anything else through the general one
+    const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const bool ok0 = ksp_abs_range_key(re[i], im[i]) & KSP_ABS_RANGE_BIT;
+    const bool ok1 = i + 1 < n && (ksp_abs_range_key(re[i + 1], im[i + 1]) & KSP_ABS_RANGE_BIT);
+    if (ok0 && ok1) {
+        ksp_abs_c64_inrange_x2(re[i], im[i], re[i + 1], im[i + 1], out[i], out[i + 1]);
+        return;
+    }
+    out[i] = ok0 ? ksp_abs_c64_inrange(re[i], im[i]) : ksp_abs_c64(re[i], im[i]);
+    if (i + 1 < n)
+        out[i + 1] = ok1 ? ksp_abs_c64_inrange(re[i + 1], im[i + 1]) : ksp_abs_c64(re[i + 1], im[i + 1]);
 }
 
 extern "C" int ksp_selftest_sqrt12(int device, void *stream, float *out, int n)
@@ -36,7 +44,7 @@ extern "C" int ksp_selftest_abs(int device, void *stream, const float *re, const
     KSP_REQUIRE(re != nullptr && im != nullptr && out != nullptr && n >= 0, "bad arguments");
     KSP_CHECK(hipSetDevice(device));
     if (n == 0) return 0;
-    hipLaunchKernelGGL(selftest_abs_kernel, dim3(ksp_divup(n, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(selftest_abs_kernel, dim3(ksp_divup(n, 512)), dim3(256), 0,
                        (hipStream_t)stream, re, im, out, n);
     KSP_LAUNCH_CHECK();
     return 0;
