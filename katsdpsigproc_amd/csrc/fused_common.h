@@ -244,7 +244,7 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
                 amp[u][1] = raw[u].z;
             }
         } else {
-            ksp_abs_c64_batch<LB, MODE == KSP_FLAGS_NONE>(raw, amp);
+            ksp_abs_c64_batch<LB, MODE == KSP_FLAGS_NONE>(raw, amp, umax);
         }
 #pragma unroll
         for (int u = 0; u < LB; u++) {
@@ -256,7 +256,8 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
                 if (fl[u] & 0xffu) a0 = __builtin_nanf("");
                 if (fl[u] >> 8) a1 = __builtin_nanf("");
             }
-            umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
+            // (without input flags only the general |z| can yield a NaN: watched there)
+            if (MODE != KSP_FLAGS_NONE) umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
             if (row < C) {
                 const int idx = LY::index(row);
                 lds[(2 * q) * LY::ROW + idx] = a0;
@@ -993,18 +994,24 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
         const float t0 = thr[0], tm = thr_min;
         // mask = 2 * mask + (compare): v_cmp into vcc, v_addc folds it in
 #pragma unroll
-        for (int j = (R < 32 ? R : 32) - 1; j >= 0; j--) {
-            asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                : "+v"(g_lo) : "v"(dev[j]), "v"(t0) : "vcc");
+        for (int j = (R < 32 ? R : 32) - 1; j >= 0; j--)
             asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                 : "+v"(e_lo) : "v"(dev[j]), "v"(tm) : "vcc");
-        }
 #pragma unroll
-        for (int j = R - 1; j >= 32; j--) {
-            asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                : "+v"(g_hi) : "v"(dev[j < R ? j : 0]), "v"(t0) : "vcc");
+        for (int j = R - 1; j >= 32; j--)
             asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                 : "+v"(e_hi) : "v"(dev[j < R ? j : 0]), "v"(tm) : "vcc");
+        // (dmax is the lane's largest deviation: no lane above thr_0 -- data without strong
+        // interference -- means no sample above it, and gt0 stays empty)
+        if (ksp_any(dmax > t0)) {
+#pragma unroll
+            for (int j = (R < 32 ? R : 32) - 1; j >= 0; j--)
+                asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                    : "+v"(g_lo) : "v"(dev[j]), "v"(t0) : "vcc");
+#pragma unroll
+            for (int j = R - 1; j >= 32; j--)
+                asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                    : "+v"(g_hi) : "v"(dev[j < R ? j : 0]), "v"(t0) : "vcc");
         }
         gt0 = ((unsigned long long)g_hi << 32) | g_lo;
         ge = ((unsigned long long)e_hi << 32) | e_lo;

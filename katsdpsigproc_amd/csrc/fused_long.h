@@ -116,7 +116,7 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
     };
     auto finish = [&](const float4 (&raw)[LB], const unsigned (&fl)[LB], int rbase) {
         float amp[LB][2];
-        ksp_abs_c64_batch<LB, MODE == KSP_FLAGS_NONE>(raw, amp);
+        ksp_abs_c64_batch<LB, MODE == KSP_FLAGS_NONE>(raw, amp, umax);
 #pragma unroll
         for (int u = 0; u < LB; u++) {
             const int row = rbase + r0 + u * RSTEP;
@@ -127,7 +127,8 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
                 if (fl[u] & 0xffu) a0 = __builtin_nanf("");
                 if (fl[u] >> 8) a1 = __builtin_nanf("");
             }
-            umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
+            // (without input flags only the general |z| can yield a NaN: watched there)
+            if (MODE != KSP_FLAGS_NONE) umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
             if (row < C) {
                 const int idx = long_index(row);
                 row_a[idx] = a0;

@@ -146,14 +146,19 @@ __device__ __forceinline__ void ksp_abs_c64_inrange_x2(float re0, float im0, flo
 // PACKED selects the two-at-once form of the short division (measured 3.6 % faster for the
 // kernel without input flags, 1 % slower when the other wavefront of the SIMD runs the
 // sorted-window median, i.e. with input flags).
+// Returns whether the batch took the short division (then every amplitude is finite).
+// `nan_watch` accumulates the largest bit pattern among the amplitudes of batches that took
+// the general form (patterns above 0x7f800000 are NaNs).
 template <int N, bool PACKED = true>
-__device__ __forceinline__ void ksp_abs_c64_batch(const float4 (&v)[N], float (&amp)[N][2])
+__device__ __forceinline__ bool ksp_abs_c64_batch(const float4 (&v)[N], float (&amp)[N][2],
+                                                  unsigned &nan_watch)
 {
     unsigned key = ~0u;
 #pragma unroll
     for (int u = 0; u < N; u++)
         key &= ksp_abs_range_key(v[u].x, v[u].y) & ksp_abs_range_key(v[u].z, v[u].w);
-    if (!ksp_any((key & KSP_ABS_RANGE_BIT) == 0)) {
+    const bool ordinary = !ksp_any((key & KSP_ABS_RANGE_BIT) == 0);
+    if (ordinary) {
 #pragma unroll
         for (int u = 0; u < N; u++) {
             if constexpr (PACKED) {
@@ -168,8 +173,11 @@ __device__ __forceinline__ void ksp_abs_c64_batch(const float4 (&v)[N], float (&
         for (int u = 0; u < N; u++) {
             amp[u][0] = ksp_abs_c64(v[u].x, v[u].y);
             amp[u][1] = ksp_abs_c64(v[u].z, v[u].w);
+            // (only here can an amplitude be NaN; see the callers' `umax`)
+            nan_watch = max(nan_watch, max(__float_as_uint(amp[u][0]), __float_as_uint(amp[u][1])));
         }
     }
+    return ordinary;
 }
 
 // Wavefront reductions on the DPP network (no LDS round trip, result wave-uniform):
