@@ -73,8 +73,22 @@ __global__ __launch_bounds__(256) void background_kernel(
             asm volatile("" : "+v"(mm.pinf), "+v"(mm.ninf));
             bool bad = false;
             float nx[WIDTH];
+            // WIDTH rows of the lane's baseline at once (all inside the band here): complex
+            // input goes through the batched |z| (short division in packed pairs)
+            auto fetch_rows = [&](int c0, bool clamp) {
+                if (is_amplitude) {
 #pragma unroll
-            for (int k = 0; k < WIDTH; k++) nx[k] = fetch(first + k);
+                    for (int k = 0; k < WIDTH; k++)
+                        nx[k] = ((const float *)in)[(size_t)(clamp ? min(c0 + k, channels - 1) : c0 + k) * stride + bb];
+                } else {
+                    float2 z[WIDTH];
+#pragma unroll
+                    for (int k = 0; k < WIDTH; k++)
+                        z[k] = ((const float2 *)in)[(size_t)(clamp ? min(c0 + k, channels - 1) : c0 + k) * stride + bb];
+                    ksp_abs_c64_rows<WIDTH>(z, nx);
+                }
+            };
+            fetch_rows(first, false);
             // block [base, base + WIDTH) gives the outputs base + H .. base + H + WIDTH - 1
             for (int base = first; base + H < c_end; base += WIDTH) {
                 float cu[WIDTH];
@@ -83,8 +97,7 @@ __global__ __launch_bounds__(256) void background_kernel(
                     cu[k] = nx[k];
                     bad |= cu[k] != cu[k];
                 }
-#pragma unroll
-                for (int k = 0; k < WIDTH; k++) nx[k] = fetch(min(base + WIDTH + k, channels - 1));
+                fetch_rows(base + WIDTH, true);
                 float S[MergeMedian<64, WIDTH>::S_SIZE];
                 S[mm.off(WIDTH - 1)] = cu[WIDTH - 1];
                 ksp_static_for<WIDTH - 1>([&](auto u_) {

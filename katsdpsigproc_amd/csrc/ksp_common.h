@@ -180,6 +180,27 @@ __device__ __forceinline__ bool ksp_abs_c64_batch(const float4 (&v)[N], float (&
     return ordinary;
 }
 
+// |z| of N visibilities of a lane (e.g. N consecutive rows of its baseline): the short
+// division in packed pairs when every magnitude, in every lane, is an ordinary one,
+// otherwise the general form for all of them.
+template <int N>
+__device__ __forceinline__ void ksp_abs_c64_rows(const float2 (&z)[N], float (&a)[N])
+{
+    unsigned key = ~0u;
+#pragma unroll
+    for (int k = 0; k < N; k++) key &= ksp_abs_range_key(z[k].x, z[k].y);
+    if (!ksp_any((key & KSP_ABS_RANGE_BIT) == 0)) {
+#pragma unroll
+        for (int k = 0; k + 1 < N; k += 2)
+            ksp_abs_c64_inrange_x2(z[k].x, z[k].y, z[k + 1].x, z[k + 1].y, a[k], a[k + 1]);
+        if (N & 1) a[N - 1] = ksp_abs_c64_inrange(z[N - 1].x, z[N - 1].y);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) a[k] = ksp_abs_c64(z[k].x, z[k].y);
+    }
+}
+
+
 // Wavefront reductions on the DPP network (no LDS round trip, result wave-uniform):
 // four row shifts leave each row's total in its lane 15, row_bcast:15 / row_bcast:31
 // carry the totals across rows into lane 63.

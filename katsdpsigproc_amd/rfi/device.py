@@ -141,7 +141,7 @@ class BackgroundMedianFilterDeviceTemplate(AbstractBackgroundDeviceTemplate):
     """
 
     host_class = host.BackgroundMedianFilterHost
-    autotune_version = 4
+    autotune_version = 5
     SUPPORTED_WIDTHS = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 25, 31)
 
     def __init__(self, context: AbstractContext, width: int, is_amplitude: bool = False,
