@@ -132,17 +132,40 @@ __global__ __launch_bounds__(256) void background_kernel(
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) ring[i] = __builtin_nanf("");
 
-    float nxt[WIDTH];
+    // WIDTH rows starting at channel c0 (any of them may lie outside the band): loads of
+    // values and flag bytes first, then the batched |z|, then the masks
+    auto fetch_block = [&](int c0, float (&dst)[WIDTH]) {
+        if (is_amplitude) {
 #pragma unroll
-    for (int k = 0; k < WIDTH; k++) nxt[k] = fetch(first + k);
+            for (int k = 0; k < WIDTH; k++) dst[k] = fetch(c0 + k);
+            return;
+        }
+        float2 z[WIDTH];
+        uint8_t f[WIDTH];
+#pragma unroll
+        for (int k = 0; k < WIDTH; k++) {
+            const int cc = min(max(c0 + k, 0), channels - 1);
+            z[k] = ((const float2 *)in)[(size_t)cc * stride + bb];
+            f[k] = 0;
+            if (flags_mode == KSP_FLAGS_CHANNEL)
+                f[k] = flags[cc];
+            else if (flags_mode == KSP_FLAGS_FULL)
+                f[k] = flags[(size_t)cc * flags_stride + bb];
+        }
+        ksp_abs_c64_rows<WIDTH>(z, dst);
+#pragma unroll
+        for (int k = 0; k < WIDTH; k++) {
+            const int c = c0 + k;
+            if (c < 0 || c >= channels || f[k]) dst[k] = __builtin_nanf("");
+        }
+    };
+    float nxt[WIDTH];
+    fetch_block(first, nxt);
     for (int base = first; base < last; base += WIDTH) {
         float cur[WIDTH];
 #pragma unroll
         for (int k = 0; k < WIDTH; k++) cur[k] = nxt[k];
-        if (base + WIDTH < last) {
-#pragma unroll
-            for (int k = 0; k < WIDTH; k++) nxt[k] = fetch(base + WIDTH + k);
-        }
+        if (base + WIDTH < last) fetch_block(base + WIDTH, nxt);
 #pragma unroll
         for (int k = 0; k < WIDTH; k++) {
             const int c = base + k;  // entering sample
