@@ -716,3 +716,38 @@ class TestArithmetic:
             expected = np.abs(z)
         np.testing.assert_array_equal(out, expected)  # NaN == NaN here
         np.testing.assert_array_equal(out, oracle.abs_c64(z))
+
+
+@pytest.mark.gpu
+class TestQueues:
+    """Command-queue plumbing that no operation test happens to exercise."""
+
+    def test_ordering_only_events(self, context):
+        """``enqueue_marker(ordering_only=True)``: events without time stamp or cache flush
+        still order the work of two queues (a chain of transposes hopping between them)."""
+        from katsdpsigproc_amd import transpose
+
+        rs = np.random.RandomState(3)
+        n = 1024
+        data = rs.standard_normal((n, n)).astype(np.float32)
+        q1, q2 = context.create_command_queue(), context.create_command_queue()
+        template = transpose.TransposeTemplate(context, np.float32, "float")
+        a = template.instantiate(q1, (n, n))
+        b = template.instantiate(q2, (n, n))
+        a.ensure_all_bound()
+        b.bind(src=a.buffer("dest"))
+        b.ensure_all_bound()
+        a.buffer("src").set(q1, data)
+        expected = data
+        for _ in range(20):
+            a()                                        # q1: src -> a.dest
+            m1 = q1.enqueue_marker(ordering_only=True)
+            q2.enqueue_wait_for_events([m1])
+            b()                                        # q2: a.dest -> b.dest (= the input again)
+            m2 = q2.enqueue_marker(ordering_only=True)
+            q1.enqueue_wait_for_events([m2])
+            b.buffer("dest").copy_region(q1, a.buffer("src"), np.s_[:, :], np.s_[:, :])
+        q1.finish()
+        q2.finish()
+        np.testing.assert_array_equal(a.buffer("src").get(q1), expected)
+        np.testing.assert_array_equal(b.buffer("dest").get(q2), expected)
