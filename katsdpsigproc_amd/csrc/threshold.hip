@@ -14,7 +14,9 @@
 //   2. read their VT + w - 1 values and form the w-term sums sequentially in
 //      float64 -- the order and precision of numpy.convolve in the host class
 //      (reference rfi/host.py:239-242), NOT the float32 Kogge-Stone tree of the
-//      reference kernel -- comparing against float32(threshold * w),
+//      reference kernel -- comparing against float32(threshold * w); for windows up
+//      to 8 only at the positions whose window holds a sample above the window's
+//      threshold (no other window can fire),
 //   3. exchange hit bit-masks with the left neighbour and dilate them with shifts.
 // Only full windows inside the band count (host `mode="valid"`); the reference
 // kernel's zero padding at the band edges is deliberately not reproduced.
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(256) void threshold_sum_kernel(
     static_assert(VT >= 8 && VT < 57, "neighbour exchange assumes 8 <= VT < 57");
     __shared__ float vals[TOT + MAXW];
     __shared__ unsigned long long hitmask[256];
+    __shared__ unsigned long long hotmask[256];
     __shared__ int lasthit[256];
     __shared__ uint8_t fbytes[TOT];
 
@@ -159,15 +162,46 @@ __global__ __launch_bounds__(256) void threshold_sum_kernel(
                 if ((fl >> i) & 1) vals[j0 + i] = thr;
             __syncthreads();
         }
-        // 2. sums of w consecutive values, sequential float64
+        // 2. sums of w consecutive values, sequential float64. Only where they can matter:
+        //    w values that are all <= thr sum to <= w * thr (the float64 sum of w copies of a
+        //    float32 is exact for these w, and rounding is monotone), so a window that fires
+        //    holds a sample > thr -- an unflagged one, flagged ones stand in as thr itself.
+        //    Each thread marks such samples among its VT, sees its right neighbour's marks
+        //    (windows of up to 8 reach 7 positions into them) and sums only the windows
+        //    that hold one: a handful per chunk once strong interference has been flagged
+        //    by window 1, instead of VT * (1 + 2 + 4 + 8) additions.
         unsigned long long hits = 0;
+        if (thr > 0.0f && w <= 8) {
+            unsigned long long hot = 0;
 #pragma unroll
-        for (int i = 0; i < VT; i++) {
-            double s = 0.0;
-            for (int m = 0; m < w; m++) s += (double)vals[j0 + i + m];
-            const int g = base + j0 + i;
-            const bool valid = (g >= 0) && (g + w <= channels) && (j0 + i + w <= TOT);
-            if (valid && s > limit) hits |= 1ull << i;
+            for (int i = 0; i < VT; i++) hot |= (unsigned long long)(vals[j0 + i] > thr) << i;
+            hotmask[t] = hot;
+            __syncthreads();
+            const unsigned long long next = t < 255 ? hotmask[t + 1] : 0ull;
+            const unsigned long long span = hot | (next << VT);  // VT + 7 <= 39 < 64 bits used
+            unsigned long long need = span;
+            if (w >= 2) need |= need >> 1;
+            if (w >= 4) need |= need >> 2;
+            if (w >= 8) need |= need >> 4;
+            need &= (1ull << VT) - 1;
+            while (need) {
+                const int i = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                double s = 0.0;
+                for (int m = 0; m < w; m++) s += (double)vals[j0 + i + m];
+                const int g = base + j0 + i;
+                const bool valid = (g >= 0) && (g + w <= channels) && (j0 + i + w <= TOT);
+                if (valid && s > limit) hits |= 1ull << i;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VT; i++) {
+                double s = 0.0;
+                for (int m = 0; m < w; m++) s += (double)vals[j0 + i + m];
+                const int g = base + j0 + i;
+                const bool valid = (g >= 0) && (g + w <= channels) && (j0 + i + w <= TOT);
+                if (valid && s > limit) hits |= 1ull << i;
+            }
         }
         // 3. dilate: a hit at j flags j .. j+w-1, possibly into the next thread(s)
         if (w <= 8) {

@@ -645,6 +645,7 @@ class ThresholdSumDeviceTemplate(AbstractThresholdDeviceTemplate):
 
     host_class = host.ThresholdSumHost
     transposed = True
+    autotune_version = 1
 
     def __init__(self, context: AbstractContext, n_windows: int = 4, flag_value: int = 1,
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
