@@ -213,58 +213,29 @@ __device__ __forceinline__ double mad_noise_long(const float (&dev)[NR][64], int
     unsigned eq0[NR], eq1[NR];
 #pragma unroll
     for (int g = 0; g < NR; g++) eq0[g] = eq1[g] = 0xffffffffu;
-    auto step2 = [&](int hi, int lo) {
-        unsigned z00_0[NR], z00_1[NR], z01_0[NR], z01_1[NR], z10_0[NR], z10_1[NR], z11_0[NR], z11_1[NR];
-        int c00 = 0, c01 = 0, c10 = 0;
-#pragma unroll
-        for (int g = 0; g < NR; g++) {
-            const unsigned a0 = eq0[g] & np[g][hi], a1 = eq1[g] & np[g][16 + hi];
-            z00_0[g] = a0 & np[g][lo];
-            z00_1[g] = a1 & np[g][16 + lo];
-            z01_0[g] = a0 ^ z00_0[g];
-            z01_1[g] = a1 ^ z00_1[g];
-            const unsigned b0 = eq0[g] ^ a0, b1 = eq1[g] ^ a1;
-            z10_0[g] = b0 & np[g][lo];
-            z10_1[g] = b1 & np[g][16 + lo];
-            z11_0[g] = b0 ^ z10_0[g];
-            z11_1[g] = b1 ^ z10_1[g];
-            c00 += __popc(z00_0[g]) + __popc(z00_1[g]);
-            c01 += __popc(z01_0[g]) + __popc(z01_1[g]);
-            c10 += __popc(z10_0[g]) + __popc(z10_1[g]);
-        }
-        int s01 = c00 | (c01 << 16);  // each field <= NR * 4096 < 65536
-        ksp_wave_sum2_dpp(s01, c10);
-        const int n1 = below_bin + (s01 & 0xffff), n2 = n1 + (int)((unsigned)s01 >> 16), n3 = n2 + c10;
-        const bool g1 = n1 <= rank, g2 = n2 <= rank, g3 = n3 <= rank;
-        K |= (unsigned)((int)g1 + (int)g2 + (int)g3) << lo;
-        below_bin = g3 ? n3 : g2 ? n2 : g1 ? n1 : below_bin;
-#pragma unroll
-        for (int g = 0; g < NR; g++) {
-            eq0[g] = g3 ? z11_0[g] : g2 ? z10_0[g] : g1 ? z01_0[g] : z00_0[g];
-            eq1[g] = g3 ? z11_1[g] : g2 ? z10_1[g] : g1 ? z01_1[g] : z00_1[g];
-        }
-    };
-#pragma unroll
-    for (int bit = 14; bit >= 2; bit -= 2) step2(bit, bit - 1);
-    {
+    // one bit per step (measured faster than two-bit steps in every bit-plane search here):
+    // the keys that match the prefix and have this bit clear are counted over the groups
+    auto step1 = [&](int bit) {
         unsigned z0[NR], z1[NR];
         int c = 0;
 #pragma unroll
         for (int g = 0; g < NR; g++) {
-            z0[g] = eq0[g] & np[g][0];
-            z1[g] = eq1[g] & np[g][16];
+            z0[g] = eq0[g] & np[g][bit];
+            z1[g] = eq1[g] & np[g][16 + bit];
             c += __popc(z0[g]) + __popc(z1[g]);
         }
         c = below_bin + ksp_wave_sum_dpp(c);
         const bool take = c <= rank;
-        K |= take ? 1u : 0u;
+        K |= take ? (1u << bit) : 0u;
         below_bin = take ? c : below_bin;
 #pragma unroll
         for (int g = 0; g < NR; g++) {
             eq0[g] = take ? (eq0[g] ^ z0[g]) : z0[g];
             eq1[g] = take ? (eq1[g] ^ z1[g]) : z1[g];
         }
-    }
+    };
+#pragma unroll
+    for (int bit = 14; bit >= 0; bit--) step1(bit);
     int mine = 0;
 #pragma unroll
     for (int g = 0; g < NR; g++) mine += __popc(eq0[g]) + __popc(eq1[g]);
