@@ -221,7 +221,7 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
     const int bl = b0 + 2 * q;
     const float2 *vis = (const float2 *)p.vis + bl;
     const size_t stride = (size_t)p.vis_stride;
-    unsigned umax = 0;
+    unsigned umax = 0, flag_or = 0;
     auto request = [&](float4 (&raw)[LB], unsigned (&fl)[LB], int rbase) {
 #pragma unroll
         for (int u = 0; u < LB; u++) {
@@ -256,8 +256,9 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
                 if (fl[u] & 0xffu) a0 = __builtin_nanf("");
                 if (fl[u] >> 8) a1 = __builtin_nanf("");
             }
-            // (without input flags only the general |z| can yield a NaN: watched there)
-            if (MODE != KSP_FLAGS_NONE) umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
+            // (only the general |z| can yield a NaN by itself: watched there; a flagged
+            // sample shows in its flag)
+            if (MODE != KSP_FLAGS_NONE) flag_or |= fl[u];
             if (row < C) {
                 const int idx = LY::index(row);
                 lds[(2 * q) * LY::ROW + idx] = a0;
@@ -289,7 +290,7 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
         lds[(2 * q) * LY::ROW + idx] = __builtin_nanf("");
         lds[(2 * q + 1) * LY::ROW + idx] = __builtin_nanf("");
     }
-    return umax > 0x7f800000u;
+    return umax > 0x7f800000u || flag_or != 0;
 }
 
 // ---------------------------------------------------------------------------------

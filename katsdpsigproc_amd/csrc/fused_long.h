@@ -101,7 +101,7 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
     const float2 *vis = (const float2 *)p.vis + bl;
     const size_t stride = (size_t)p.vis_stride;
     float *row_a = lds + (2 * q) * row_floats, *row_b = lds + (2 * q + 1) * row_floats;
-    unsigned umax = 0;
+    unsigned umax = 0, flag_or = 0;
     auto request = [&](float4 (&raw)[LB], unsigned (&fl)[LB], int rbase) {
 #pragma unroll
         for (int u = 0; u < LB; u++) {
@@ -127,8 +127,9 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
                 if (fl[u] & 0xffu) a0 = __builtin_nanf("");
                 if (fl[u] >> 8) a1 = __builtin_nanf("");
             }
-            // (without input flags only the general |z| can yield a NaN: watched there)
-            if (MODE != KSP_FLAGS_NONE) umax = max(umax, max(__float_as_uint(a0), __float_as_uint(a1)));
+            // (only the general |z| can yield a NaN by itself: watched there; a flagged
+            // sample shows in its flag)
+            if (MODE != KSP_FLAGS_NONE) flag_or |= fl[u];
             if (row < C) {
                 const int idx = long_index(row);
                 row_a[idx] = a0;
@@ -156,7 +157,7 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
         row_a[long_index(row)] = __builtin_nanf("");
         row_b[long_index(row)] = __builtin_nanf("");
     }
-    return umax > 0x7f800000u;
+    return umax > 0x7f800000u || flag_or != 0;
 }
 
 // ---------------------------------------------------------------------------------
