@@ -95,7 +95,9 @@ struct SortedWindow {
             // the empty asm keeps this a real branch (skipped when no lane is odd)
             // instead of eight speculated float64 instructions per step
             asm volatile("");
-            d = (float)((double)x - ((double)s[H > 0 ? H - 1 : 0] + (double)s[H]) * 0.5);
+            // x - (lo + hi) / 2 with one rounding: the sum is exact in float64, halving it
+            // is exact, so the fused form equals the host's two steps
+            d = (float)__fma_rn(-0.5, (double)s[H > 0 ? H - 1 : 0] + (double)s[H], (double)x);
         }
         return d;
     }
