@@ -9,7 +9,8 @@ ctx = accel.create_some_context(False); q = ctx.create_command_queue()
 vis, spikes, in_flags = inputs.flagger_case()
 for th in ("simple", "sum"):
     t = device.FlaggerDeviceTemplate(device.BackgroundMedianFilterDeviceTemplate(ctx, 13), device.NoiseEstMADTDeviceTemplate(ctx, 10240),
-        device.ThresholdSimpleDeviceTemplate(ctx, False) if th == "simple" else device.ThresholdSumDeviceTemplate(ctx))
+        device.ThresholdSimpleDeviceTemplate(ctx, False) if th == "simple" else device.ThresholdSumDeviceTemplate(ctx),
+        keep_deviations=True)
     fn = t.instantiate(q, *vis.shape, threshold_args={"n_sigma": 11.0}); fn.ensure_all_bound()
     fn.buffer("vis").set(q, vis); fn()
     flags = fn.buffer("flags").get(q); noise = fn.buffer("noise").get(q); dev = fn.buffer("deviations").get(q)
