@@ -46,6 +46,11 @@ int ksp_fused_long_supported(int channels, int width);
 int ksp_fused_launch_long(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
                           hipEvent_t ev1);
 
+// 4096 channels, whole strips of 8 baselines (flagger_ring.hip)
+bool ksp_ring_supported(const FusedParams &p, int width);
+int ksp_ring_launch(int width, int device, hipStream_t s, const FusedParams &p, int n_cu,
+                    hipEvent_t ev0, hipEvent_t ev1);
+
 static int ksp_fused_launch_other_width(int width, int device, hipStream_t s,
                                         const FusedParams &p, hipEvent_t ev0, hipEvent_t ev1)
 {
@@ -122,6 +127,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     p.flag_value = flag_value;
     p.n_strips = ksp_divup(baselines, FUSED_STRIP);
     p.work = (unsigned *)workspace;
+    int n_cu = 0;
     p.n_dyn = 0;
     if (workspace != nullptr && p.n_strips >= 2048) p.n_dyn = (p.n_strips >> FUSED_DYN_SHIFT) & ~63;
     p.n_static = p.n_strips - p.n_dyn;
@@ -134,6 +140,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
             if (device >= 0 && device < 64) cus[device].store(n, std::memory_order_relaxed);
         }
         p.first_round = 2 * n;
+        n_cu = n;
     }
 #ifdef KSP_DIAG
     p.trace = nullptr;
@@ -147,6 +154,28 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
         p.scales[k] = (scales64 != nullptr && k < n_windows) ? scales64[k] : 0.0;
 
     hipStream_t s = (hipStream_t)stream;
+    // The persistent ring kernel takes the whole strips of 8 baselines of a 4096-channel
+    // launch without input flags; a ragged remainder (< 8 baselines) goes to the
+    // 4-baseline kernel. KSP_FUSED_NO_RING=1 (diagnostics) keeps everything on the latter.
+    static const bool no_ring = getenv("KSP_FUSED_NO_RING") != nullptr;
+    if (!no_ring && width == 13 && ksp_ring_supported(p, width)) {
+        KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines, s));
+        const int whole = baselines - baselines % 8;
+        if (whole < baselines) {
+            FusedParams t = p;
+            t.vis = (const float2 *)p.vis + whole;
+            t.flags = p.flags + whole;
+            if (p.noise != nullptr) t.noise = p.noise + whole;
+            t.baselines = baselines - whole;
+            t.n_strips = ksp_divup(t.baselines, FUSED_STRIP);
+            t.n_dyn = 0;
+            t.n_static = t.n_strips;
+            t.dyn_blocks = 0;
+            const int rc = launch_fused<64, 13>(device, s, t, nullptr, nullptr, false);
+            if (rc != 0) return rc;
+        }
+        return ksp_ring_launch(width, device, s, p, n_cu, ev0, ev1);
+    }
     if (channels > 4096) return ksp_fused_launch_long(device, s, p, ev0, ev1);
     if (width != 13) return ksp_fused_launch_other_width(width, device, s, p, ev0, ev1);
     if (channels <= 64 * 4) return launch_fused<4, 13>(device, s, p, ev0, ev1);

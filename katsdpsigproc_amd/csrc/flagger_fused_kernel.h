@@ -173,13 +173,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
 // =================================================================================
 template <int R, int WIDTH>
 inline int launch_fused(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
-                        hipEvent_t ev1)
+                        hipEvent_t ev1, bool zero_fill = true)
 {
     using LY = FusedLayout<R>;
     const size_t lds_bytes = LY::LDS_BYTES;
     // all flags start at zero; the kernels only write the (rare) non-zero ones
-    KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
-                             s));
+    if (zero_fill)
+        KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
+                                 s));
     auto kern = flagger_fused_kernel<R, WIDTH>;
     // the opt-in to more than 64 KiB of dynamic LDS is per device (one context per
     // device in one process is a supported arrangement, reference doc/user/init.rst:4-6)
