@@ -372,14 +372,18 @@ __device__ __forceinline__ double exact_dev(int c, Fetch &&fetch)
     constexpr int H = WIDTH / 2;
     float pinf = __builtin_inff(), ninf = -__builtin_inff();
     asm volatile("" : "+v"(pinf), "+v"(ninf));  // opaque: med3 with them stays one instruction
+    // (all samples first: where `fetch` reads global memory the loads are then in flight
+    // together instead of one per insertion)
+    float a[WIDTH];
+#pragma unroll
+    for (int k = 0; k < WIDTH; k++) a[k] = fetch(c - H + k);
     float v[WIDTH];
     int n = 0;
 #pragma unroll
     for (int k = 0; k < WIDTH; k++) {
-        const float a = fetch(c - H + k);
-        const bool ok = a == a;
+        const bool ok = a[k] == a[k];
         n += ok;
-        const float x = ok ? a : pinf;
+        const float x = ok ? a[k] : pinf;
         // insert x into the sorted v[0 .. k)
         float out[WIDTH];
         if (k == 0) {
@@ -393,7 +397,7 @@ __device__ __forceinline__ double exact_dev(int c, Fetch &&fetch)
 #pragma unroll
         for (int i = 0; i <= k; i++) v[i] = out[i];
     }
-    const float centre = fetch(c);
+    const float centre = a[H];
     float lo = v[0], hi = v[0];
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) {
@@ -562,13 +566,52 @@ __device__ __forceinline__ void rank_lanes64(double x, int n, int r, int lane, d
     prev = have_prev ? ksp_bcast(x, __ffsll((long long)ksp_ballot(live && cnt == r - 1)) - 1) : 0.0;
 }
 
+// dev[j] for a lane-varying j: a binary tree of selects, one level per bit of j (6 compares
+// and 63 v_cndmask; a register array cannot be indexed per lane).
+__device__ __forceinline__ float ksp_select64(const float (&dev)[64], int j)
+{
+    // (v_cndmask written out: left to the optimiser, a select between two array elements
+    // becomes an element with a run-time index and the arrays move to scratch memory)
+    auto pick = [](unsigned long long mask, float a, float b) -> float {  // mask ? b : a
+        float r;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+        return r;
+    };
+    const unsigned long long m0 = ksp_ballot(j & 1), m1 = ksp_ballot(j & 2), m2 = ksp_ballot(j & 4),
+                             m3 = ksp_ballot(j & 8), m4 = ksp_ballot(j & 16), m5 = ksp_ballot(j & 32);
+    float t32[32], t16[16], t8[8], t4[4];
+#pragma unroll
+    for (int i = 0; i < 32; i++) t32[i] = pick(m0, dev[2 * i], dev[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) t16[i] = pick(m1, t32[2 * i], t32[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) t8[i] = pick(m2, t16[2 * i], t16[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) t4[i] = pick(m3, t8[2 * i], t8[2 * i + 1]);
+    return pick(m5, pick(m4, t4[0], t4[1]), pick(m4, t4[2], t4[3]));
+}
+template <int R>
+__device__ __forceinline__ float ksp_select_dev(const float (&dev)[R], int j)
+{
+    if constexpr (R == 64)
+        return ksp_select64(dev, j);
+    else
+        return 0.0f;  // (never asked for: HAVE_EXACT needs R == 64)
+}
+
 // `list` is this wavefront's private candidate list in LDS (LIST_CAP doubles).
+// HAVE_EXACT: the caller knows which deviations are exact as they stand -- bit j of `exact`
+// set means float64(dev[j]) IS the host's float64 deviation of channel c0 + j (a float32
+// difference that did not round, Sterbenz) -- and exact_dev() is then only asked for the
+// others: the usual case needs no amplitude at all.
 // Returns the float64 noise estimate (NaN when every deviation is zero).
-template <int R, int WIDTH, int LIST_CAP, class Fetch>
+template <int R, int WIDTH, int LIST_CAP, bool HAVE_EXACT = false, class Fetch>
 __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, double *list,
                                             Fetch &&fetch, int debug_stop = 0,
-                                            unsigned long long *trace = nullptr)
+                                            unsigned long long *trace = nullptr,
+                                            unsigned long long exact = 0)
 {
+    static_assert(!HAVE_EXACT || R == 64, "exactness masks are 64 bits, one per sample of a lane");
     constexpr int NP = R / 2;
     const int c0 = lane * R;
     // dev[j] behind an opaque copy, for the rarely taken paths below: without it the
@@ -831,35 +874,76 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             if (hit) lc[pos] = channel;
             n += __popcll(m);
         };
-        if constexpr (R == 64) {
-            // every lane knows its own hits (eq0 / eq1); a prefix sum over the lanes
-            // gives each lane its first slot in the list and the lanes fill in their
-            // (zero to a few) channels on their own -- no per-sample wave operations
+        double x;
+        if constexpr (R == 64 && HAVE_EXACT) {
+            // every lane knows its own hits (eq0 / eq1): it hands out channel, exactness and
+            // |float32 deviation| of each (the deviation through ksp_select64: as many rounds
+            // as the busiest lane has hits)
             const int mine = __popc(eq0) + __popc(eq1);
             const int incl = ksp_wave_scan_dpp(mine);
             n = __builtin_amdgcn_readlane(incl, 63);
             int pos = incl - mine;
             unsigned h0 = eq0, h1 = eq1;
-            while (h0 | h1) {  // divergent: as many rounds as the busiest lane has hits
+            while (ksp_any((h0 | h1) != 0)) {
+                const bool has = (h0 | h1) != 0;
+                int j = 0;
                 if (h0) {
-                    lc[pos++] = c0 + 2 * (__ffs((int)h0) - 1);
+                    j = 2 * (__ffs((int)h0) - 1);
                     h0 &= h0 - 1;
-                } else {
-                    lc[pos++] = c0 + 2 * (__ffs((int)h1) - 1) + 1;
+                } else if (h1) {
+                    j = 2 * (__ffs((int)h1) - 1) + 1;
                     h1 &= h1 - 1;
                 }
+                const float v = ksp_select_dev<R>(dev, j);
+                if (has) {
+                    lc[2 * pos] = (c0 + j) | (((exact >> j) & 1) ? (int)0x80000000 : 0);
+                    lc[2 * pos + 1] = (int)(__float_as_uint(v) & 0x7fffffffu);
+                    pos++;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int slot = lane < n ? lane : 0;
+            const int e0 = lc[2 * slot];
+            x = (double)__int_as_float(lc[2 * slot + 1]);
+            const bool inexact = lane < n && e0 >= 0;
+            stamp(11);
+            if (debug_stop == 33) return x;
+            if (ksp_any(inexact)) {
+                const double xe = fabs(exact_dev<WIDTH>(e0 & 0x7fffffff, fetch));
+                x = inexact ? xe : x;
             }
         } else {
+            if constexpr (R == 64) {
+                // every lane knows its own hits (eq0 / eq1); a prefix sum over the lanes
+                // gives each lane its first slot in the list and the lanes fill in their
+                // (zero to a few) channels on their own -- no per-sample wave operations
+                const int mine = __popc(eq0) + __popc(eq1);
+                const int incl = ksp_wave_scan_dpp(mine);
+                n = __builtin_amdgcn_readlane(incl, 63);
+                int pos = incl - mine;
+                unsigned h0 = eq0, h1 = eq1;
+                while (h0 | h1) {  // divergent: as many rounds as the busiest lane has hits
+                    if (h0) {
+                        lc[pos++] = c0 + 2 * (__ffs((int)h0) - 1);
+                        h0 &= h0 - 1;
+                    } else {
+                        lc[pos++] = c0 + 2 * (__ffs((int)h1) - 1) + 1;
+                        h1 &= h1 - 1;
+                    }
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < R; j++) place(key_of(j) == K, c0 + j);
+                for (int j = 0; j < R; j++) place(key_of(j) == K, c0 + j);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int c = lc[lane < n ? lane : 0];
+            stamp(11);
+            if (debug_stop == 33) return (double)c;
+            // one exact recomputation serves every candidate (one per lane)
+            x = fabs(exact_dev<WIDTH>(c, fetch));
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int c = lc[lane < n ? lane : 0];
-        stamp(11);
-        if (debug_stop == 33) return (double)c;
-        // one exact recomputation serves every candidate (one per lane)
-        const double x = fabs(exact_dev<WIDTH>(c, fetch));
         stamp(12);
         rank_lanes64(x, n, r, lane, xk, prev, have_prev);
         stamp(13);
@@ -891,22 +975,32 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
 #pragma unroll
         for (int j = 0; j < R; j++)
             if (((bm >> j) & 1) && fabsf(dv(j)) == b32) top |= 1ull << j;
-        const int n2 = gather_exact<WIDTH>(top, c0, list, 0, LIST_CAP, fetch);
-        double below_max = 0.0;
-        for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
-        prev = ksp_wave_max(below_max);
-        __builtin_amdgcn_wave_barrier();
-        if (n2 > LIST_CAP) {
-            // more ties at b32 than the list holds: largest exact value, no list
-            double m = 0.0;
-            while (__any(top != 0)) {
-                const bool has = top != 0;
-                const int j = has ? __ffsll((long long)top) - 1 : 0;
-                top &= top - 1;
-                const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
-                m = has ? fmax(m, x) : m;
+        bool recompute = true;
+        if constexpr (HAVE_EXACT) {
+            // every sample at that value exact as it stands: the value itself
+            if (!ksp_any((top & ~exact) != 0)) {
+                prev = (double)b32;
+                recompute = false;
             }
-            prev = ksp_wave_max(m);
+        }
+        if (recompute) {
+            const int n2 = gather_exact<WIDTH>(top, c0, list, 0, LIST_CAP, fetch);
+            double below_max = 0.0;
+            for (int i = lane; i < min(n2, LIST_CAP); i += 64) below_max = fmax(below_max, list[i]);
+            prev = ksp_wave_max(below_max);
+            __builtin_amdgcn_wave_barrier();
+            if (n2 > LIST_CAP) {
+                // more ties at b32 than the list holds: largest exact value, no list
+                double m = 0.0;
+                while (__any(top != 0)) {
+                    const bool has = top != 0;
+                    const int j = has ? __ffsll((long long)top) - 1 : 0;
+                    top &= top - 1;
+                    const double x = fabs(exact_dev<WIDTH>(c0 + j, fetch));
+                    m = has ? fmax(m, x) : m;
+                }
+                prev = ksp_wave_max(m);
+            }
         }
     }
     stamp(14);

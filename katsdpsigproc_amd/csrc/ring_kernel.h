@@ -32,10 +32,18 @@
 #pragma once
 #include "fused_common.h"
 
+#ifndef RING_STOP
+#define RING_STOP 0  // diagnostic builds: 1 = ring and |z| only, 2 = + median, 3 = + MAD
+#endif
 #define RING_THREADS 512
 #define RING_STRIP 8
 #define RING_NSLOT 32            // step slots in the ring
+#ifndef RING_G
 #define RING_G 4                 // steps per chunk
+#endif
+#ifndef RING_STAGGER
+#define RING_STAGGER 0           // x 8128 cycles: every other workgroup of an XCD starts late (diagnostic)
+#endif
 #define RING_SLOT_BYTES 4096     // 64 rows x 64 B
 #define RING_LIST_DOUBLES 256    // per wavefront (MAD candidate list)
 #define RING_XCD_GROUP 8         // strips per XCD run
@@ -47,6 +55,13 @@ struct RingLayout {
     static constexpr size_t LDS_BYTES = RING_BYTES + LIST_BYTES + CTRL_BYTES;
 };
 
+#ifdef RING_TRACE
+// diagnostic builds (-DRING_TRACE): shader-clock stamps [workgroup][wavefront][strip][8],
+// dumped by launch_ring to the file named by KSP_RING_TRACE (tools/trace_ring.py)
+#define RING_TRACE_STRIPS 24
+__device__ unsigned long long ring_trace_buf[256 * 8 * RING_TRACE_STRIPS * 8];
+#endif
+
 // workspace words used by this kernel (the 4-baseline kernels use [0], [1])
 #define RING_WORK_LIST 2   // [2 .. 9]: next ticket of XCD list x
 #define RING_WORK_DONE 10  // workgroups finished
@@ -57,14 +72,15 @@ __device__ __forceinline__ int ring_strip_of(int x, int t)
     return ((t / RING_XCD_GROUP) * 8 + x) * RING_XCD_GROUP + (t % RING_XCD_GROUP);
 }
 
-// Next strip for a workgroup of XCD list `x`: its own list first, then the others'.
-// Returns -1 when every list is exhausted. One lane calls this.
-__device__ __forceinline__ int ring_take(unsigned *work, int x, int n_strips)
+// Next strip for a workgroup of XCD list `x`, from the counters: its own list first, then the
+// others'. Tickets count from `t0` (what the static part of the schedule has used of every
+// list). Returns -1 when every list is exhausted. One lane calls this.
+__device__ __forceinline__ int ring_take(unsigned *work, int x, int n_strips, int t0)
 {
     for (int k = 0; k < 8; k++) {
         const int xx = (x + k) & 7;
         // (a list that has been seen exhausted keeps counting up: harmless, reset at the end)
-        const int t = (int)atomicAdd(&work[RING_WORK_LIST + xx], 1u);
+        const int t = t0 + (int)atomicAdd(&work[RING_WORK_LIST + xx], 1u);
         const int s = ring_strip_of(xx, t);
         if (s < n_strips) return s;
     }
@@ -94,7 +110,8 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
     static_assert(W % 2 == 1 && W <= 13 && 2 * H <= G * 3, "merging median only");
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: so is all that follows from it)
     const int C = p.channels;  // == 4096
     double *list = (double *)(lds + RingLayout::RING_BYTES) + wave * RING_LIST_DOUBLES;
     int *ctrl = (int *)(lds + RingLayout::RING_BYTES + RingLayout::LIST_BYTES);
@@ -116,40 +133,54 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
     typedef const __attribute__((address_space(3))) unsigned long long lds_cu64;
     lds_cchar *lds3 = (lds_cchar *)(lds_void *)lds;
 
-    auto issue = [&](const char *strip_base, int j) {  // this wavefront's piece of step j
-        // (the row pitch behind an opaque copy: otherwise all 64 products j * pitch are
-        // hoisted out of the strip loop and spilled)
-        unsigned long long rb = row_bytes;
-        asm volatile("" : "+s"(rb));
-        const unsigned long long sa = (unsigned long long)strip_base + (unsigned long long)j * rb;  // (wave-uniform)
-        const unsigned long long src =
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sa >> 32)) << 32) |
-            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)sa);  // (the builtin returns int)
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (j % NSLOT) * RING_SLOT_BYTES + q * 1024);
+    // This wavefront's pieces, in the order it requests them: steps par, par + 2, ... of a
+    // strip, then the same of the next one -- a running source address that advances by two
+    // rows per piece and jumps to the next strip when step `par` of that strip comes up.
+    unsigned long long run_src = 0;
+    const unsigned long long rb2 = 2 * (unsigned long long)row_bytes;
+    const unsigned piece_base = __builtin_amdgcn_readfirstlane(lds_base + q * 1024);
+    auto issue = [&](int slot) {  // the piece at run_src -> ring slot `slot` (+ par)
+        // (opaque per use: the 32 destination addresses are otherwise kept in scalar
+        // registers across the strip loop and spilled)
+        unsigned pb = piece_base;
+        asm volatile("" : "+s"(pb));
+        const unsigned dst = pb + (unsigned)(slot + par) * RING_SLOT_BYTES;
         // Inline assembly: the compiler orders every later LDS read behind an LDS-DMA it
         // knows about with s_waitcnt vmcnt(0), which would serialise the ring. M0 (the LDS
         // destination) is restored for the compiler.
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
+                     : "=&s"(keep) : "v"(lane_off), "s"(run_src), "s"(dst) : "memory");
+        run_src += rb2;
     };
     auto strip_base = [&](int strip) -> const char * {
         return (const char *)p.vis + (size_t)strip * (RING_STRIP * 8);
     };
 
-    // ---- schedule: two strips ahead (the next strip's address is needed half way through
-    // this one, and no vector-memory instruction other than the DMA may be issued while
-    // the ring is being consumed: the waits below count them)
+    // ---- schedule. The first p.n_static strips of a workgroup are fixed: strip k of
+    // workgroup b is ticket k * (grid / 8) + b / 8 of list b % 8 (the workgroups b, b + 8, ...
+    // share an XCD). The rest come from the per-list counters, so that an XCD that is ahead
+    // takes more: a ticket costs a returning atomic, whose wait also waits for every LDS-DMA
+    // request this wavefront has in flight -- hence only the tail of the launch pays it.
+    // Strips are known two ahead (the next strip's address is needed half way through this
+    // one).
     const int xcd = blockIdx.x & 7;
+    const int per_list = (int)gridDim.x >> 3;
+    const int t0 = p.n_static * per_list;  // tickets of every list used by the static part
+    auto static_strip = [&](int k) { return ring_strip_of(xcd, k * per_list + ((int)blockIdx.x >> 3)); };
     if (tid == 0) {
-        ctrl[0] = ring_take(p.work, xcd, p.n_strips);
-        ctrl[1] = ctrl[0] >= 0 ? ring_take(p.work, xcd, p.n_strips) : -1;
+        int s0 = 0 < p.n_static ? static_strip(0) : ring_take(p.work, xcd, p.n_strips, t0);
+        int s1 = -1;
+        if (s0 >= 0) s1 = 1 < p.n_static ? static_strip(1) : ring_take(p.work, xcd, p.n_strips, t0);
+        ctrl[0] = s0;
+        ctrl[1] = s1;
     }
     __syncthreads();
     // (read back through readfirstlane: strip numbers and everything derived from them live
     // in scalar registers)
     int cur = __builtin_amdgcn_readfirstlane(ctrl[0]), nxt = __builtin_amdgcn_readfirstlane(ctrl[1]);
+    int k_strip = 0;  // strips this workgroup has started before `cur`
     auto finish = [&]() {
         if (tid == 0 && atomicAdd(&p.work[RING_WORK_DONE], 1u) == gridDim.x - 1u) {
 #pragma unroll
@@ -160,16 +191,37 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         finish();
         return;
     }
-    {
-        const char *b = strip_base(cur);
-        // (steps NSLOT - G .. NSLOT - 1 are requested behind the first barrier, as for every
-        // later strip)
-        for (int j = par; j < NSLOT - G; j += 2) issue(b, j);
+#if RING_STAGGER > 0
+    if ((blockIdx.x >> 3) & 1) {
+#pragma unroll
+        for (int i = 0; i < RING_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
     }
+#endif
+    auto start_of = [&](int strip) -> unsigned long long {  // step `par` of a strip
+        const unsigned long long a = (unsigned long long)strip_base(strip) + (unsigned long long)par * row_bytes;
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);  // (the builtin returns int)
+    };
+    run_src = start_of(cur);
+    // (steps NSLOT - G .. NSLOT - 1 are requested behind the first barrier, as for every
+    // later strip)
+#pragma unroll
+    for (int j = 0; j < NSLOT - G; j += 2) issue(j);
     const float nanv = __builtin_nanf("");
     const float2 *visf = (const float2 *)p.vis;
 
     const int lane_id = lane;
+#ifdef RING_TRACE
+    int trace_it = 0;
+#define RING_STAMP(i)                                                                              \
+    do {                                                                                           \
+        if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256)                      \
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + (i)] =   \
+                __builtin_amdgcn_s_memtime();                                                      \
+    } while (0)
+#else
+#define RING_STAMP(i) do { } while (0)
+#endif
     for (;;) {
         // (the lane number behind an opaque copy per strip: the MAD's 64 lane masks and the
         // like are otherwise computed once, ahead of the loop, and spilled)
@@ -177,8 +229,7 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         asm volatile("" : "+v"(lane));
         const int bl = cur * RING_STRIP + wave;
         const bool more = nxt >= 0;
-        const char *base_cur = strip_base(cur);
-        const char *base_nxt = strip_base(more ? nxt : cur);
+        const unsigned long long start_nxt = start_of(more ? nxt : cur);
         // exact recomputations read the visibilities again (branch-free: the loads of a
         // window are all issued before the first is used)
         auto fetch = [&](int c) -> float {
@@ -192,6 +243,12 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         // all but the N youngest, so the counted waits below only need a LOWER bound on what
         // was issued after the pieces they wait for: the stores, re-reads and tickets of the
         // phases in between make them wait longer, never shorter.)
+        RING_STAMP(0);
+#ifdef RING_TRACE
+        unsigned long long wait_dma = 0, wait_bar = 0;
+        if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256)
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
         float amp[STEPS];
         unsigned umax = 0;
         // chunk c: make its 4 steps visible, refill the previous chunk's slots, |z|
@@ -200,22 +257,37 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
             // this wavefront's pieces of chunk c have landed: it has issued those of chunks
             // c + 1 .. c + K - 2 after them (the last strip stops at its own last chunk)
             constexpr int AH = (K - 2) * PER_CHUNK;
+#ifdef RING_TRACE
+            unsigned long long w0;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0));
+#endif
             if (more || (c + K - 2) * G + G <= STEPS)
                 __builtin_amdgcn_s_waitcnt(0x0070 | (AH & 15) | ((AH >> 4) << 14));
             else
                 __builtin_amdgcn_s_waitcnt(0x0070);
+#ifdef RING_TRACE
+            unsigned long long w1;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1));
+#endif
             __syncthreads();
+#ifdef RING_TRACE
+            unsigned long long w2;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w2));
+            wait_dma += w1 - w0;
+            wait_bar += w2 - w1;
+#endif
             // the slots of chunk c - 1 (every wavefront has read them) take the steps
             // NSLOT further on; chunk -1 = the previous strip's last chunk
-#pragma unroll
-            for (int g = par; g < G; g += 2) {
+            ksp_static_for<G / 2>([&](auto u_) {
                 constexpr int cm = (c + NCHUNK - 1) % NCHUNK;
-                const int j = cm * G + g + NSLOT - (c == 0 ? STEPS : 0);
-                if (j < STEPS)
-                    issue(base_cur, j);
-                else if (more)
-                    issue(base_nxt, j - STEPS);
-            }
+                constexpr int j = cm * G + 2 * decltype(u_)::value + NSLOT - (c == 0 ? STEPS : 0);
+                if constexpr (j < STEPS) {
+                    issue(j % NSLOT);
+                } else if (more) {
+                    if constexpr (j == STEPS) run_src = start_nxt;
+                    issue(j % NSLOT);
+                }
+            });
             float2 z[G];
             unsigned ro = rd_off;
             asm volatile("" : "+v"(ro));  // (opaque: or 16 slot addresses are kept in registers for good)
@@ -244,6 +316,35 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
 
         float dev[R];
         float dmax;
+        // Which deviations are exact as they stand (fused_common.h, mad_noise HAVE_EXACT)? x and
+        // m are multiples of the unit in the last place of whichever has the smaller exponent
+        // e, and so is their difference D; it fits 24 bits, and the float32 subtraction does
+        // not round, if and only if |D| < 2^(e + 1) -- and then d = D, otherwise |d| >= 2^(e + 1)
+        // as well: d is exact exactly when its exponent is at most e, i.e. |d| <= the largest
+        // float32 with exponent e. One bit per output, shifted into two accumulators in the
+        // order the outputs appear. (NaN compares false: not exact.)
+        unsigned ex_a = 0, ex_b = 0;
+        auto note_exact = [&](unsigned &acc, float x, float m, float d) {
+            unsigned t;
+            asm("v_min_u32 %1, %2, %3\n\tv_or_b32 %1, 0x7fffff, %1\n\t"
+                "v_cmp_ge_f32 vcc, %1, |%4|\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(acc), "=&v"(t)
+                : "v"(__float_as_uint(x)), "v"(__float_as_uint(m)), "v"(d)
+                : "vcc");
+        };
+#if RING_STOP == 1
+        // diagnostic: ring + |z| only
+        dmax = 0.f;
+        ksp_static_for<NCHUNK>([&](auto c_) {
+            load_chunk(c_);
+            constexpr int c = decltype(c_)::value;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                dev[c * G + g] = amp[c * G + g];
+                dmax += amp[c * G + g];
+            }
+        });
+#else
         {
             MergeMedian<R, W> mm;
             mm.pinf = __builtin_inff();
@@ -308,6 +409,10 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                         // (pinned: the optimiser otherwise sinks the whole median below the
                         // last chunk, next to the first use of the deviations)
                         asm volatile("" : "+v"(d));
+                        if constexpr (jv < 32)
+                            note_exact(ex_a, xc, med, d);
+                        else
+                            note_exact(ex_b, xc, med, d);
                         dmax = mm.vmax(dmax, d);
                         dev[j] = d;
                     }
@@ -360,10 +465,38 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                         const float lo = mm.template rank<H - j, j + H + 1, H - 1>(&SL[soff(j)], PL);
                         if (first) d = (float)((double)xc - ((double)lo + (double)med) * 0.5);
                     }
+                    note_exact(ex_b, xc, med, d);
                     dmax = mm.vmax(dmax, d);
                     dev[j] = d;
                 });
             }
+        }
+#endif
+        RING_STAMP(1);
+#ifdef RING_TRACE
+        if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256) {
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 5] = wait_dma;
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 6] = wait_bar;
+        }
+#endif
+        // bit j of `exact`: output j. ex_a holds outputs H .. H + 31 (the first at bit 31),
+        // ex_b outputs H + 32 .. 63, then 0 .. H - 1. Windows with an even number of samples
+        // (band edges) average two samples in float64: never exact in this sense.
+        unsigned long long exact;
+        {
+            const unsigned ra = __builtin_bitreverse32(ex_a), rb = __builtin_bitreverse32(ex_b);
+            exact = ((unsigned long long)ra << H) |
+                    ((unsigned long long)(rb & ((1u << (32 - H)) - 1u)) << (H + 32)) |
+                    (unsigned long long)(rb >> (32 - H));
+            unsigned long long first_odd = 0, last_odd = 0;
+#pragma unroll
+            for (int j = 0; j < H; j++)
+                if ((H - j) & 1) first_odd |= 1ull << j;
+#pragma unroll
+            for (int j = R - H; j < R; j++)
+                if ((j + H - R + 1) & 1) last_odd |= 1ull << j;
+            if (lane == 0) exact &= ~first_odd;
+            if (lane == 63) exact &= ~last_odd;
         }
         // From here on the ring is not touched; the requests for the next strip stay in
         // flight. A baseline with a NaN amplitude (NaN or infinite input) takes the general
@@ -375,29 +508,59 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
 #pragma unroll
             for (int i = 0; i < R + 2 * H; i++) a2[i] = fetch(c_first + i);
             median_phase_src<R, W>([&](int i) { return a2[i + H]; }, dev, dmax);
+            exact = 0;
         }
-        // next but one strip: the ticket of the own list is in flight during the MAD
+        // next but one strip, if it comes from the counters: the ticket of the own list is in
+        // flight during the MAD
+        const bool ticket = more && k_strip + 2 >= p.n_static;
         unsigned t_own = 0;
-        if (tid == 0 && more) t_own = atomicAdd(&p.work[RING_WORK_LIST + xcd], 1u);
+        if (tid == 0 && ticket) t_own = atomicAdd(&p.work[RING_WORK_LIST + xcd], 1u);
 
-        const double noise64 = mad_noise<R, W, RING_LIST_DOUBLES>(dev, lane, list, fetch);
+#if RING_STOP == 1 || RING_STOP == 2
+        // diagnostic: no MAD, no thresholds (keep the deviations alive)
+        {
+            float acc = dmax;
+#pragma unroll
+            for (int j = 0; j < R; j++) acc += dev[j];
+            if (acc == 12345.678f && p.noise != nullptr) p.noise[bl] = acc;
+        }
+#else
+        const double noise64 = mad_noise<R, W, RING_LIST_DOUBLES, true>(dev, lane, list, fetch, RING_STOP > 30 ? RING_STOP : 0,
+                                                                      nullptr, exact);
         if (lane == 0 && p.noise != nullptr) p.noise[bl] = (float)noise64;
+        RING_STAMP(2);
+#if RING_STOP == 3 || RING_STOP > 30
+        if (noise64 == 12345.678 && p.noise != nullptr) p.noise[bl] = dmax;
+#else
         const unsigned long long fl = threshold_flags<R, W>(p, dev, dmax, noise64, lane, C, fetch);
         write_flags(p, fl, lane * R, bl, C);
+        RING_STAMP(3);
+#endif
+#endif
 
-        if (tid == 0) {
-            int take = -1;
-            if (more) {
-                take = ring_strip_of(xcd, (int)t_own);
-                if (take >= p.n_strips) take = ring_take(p.work, (xcd + 1) & 7, p.n_strips);
-            }
-            ctrl[2] = take;
-        }
+#ifdef RING_TRACE
+        if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256)
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 7] = (unsigned long long)cur + 1;
+        trace_it++;
+#endif
         if (!more) break;
-        __syncthreads();  // (also keeps a fast wavefront out of the ring of a slow one's strip)
         cur = nxt;
-        nxt = __builtin_amdgcn_readfirstlane(ctrl[2]);
-        __syncthreads();  // ctrl[2] is read before thread 0 can overwrite it
+        if (!ticket) {
+            nxt = static_strip(k_strip + 2);
+#ifdef RING_END_SYNC
+            __syncthreads();
+#endif
+        } else {
+            if (tid == 0) {
+                int take = ring_strip_of(xcd, t0 + (int)t_own);
+                if (take >= p.n_strips) take = ring_take(p.work, (xcd + 1) & 7, p.n_strips, t0);
+                ctrl[2] = take;
+            }
+            __syncthreads();
+            nxt = __builtin_amdgcn_readfirstlane(ctrl[2]);
+            __syncthreads();  // ctrl[2] is read before thread 0 can overwrite it
+        }
+        k_strip++;
     }
     finish();
 }
@@ -427,11 +590,47 @@ inline int launch_ring(int device, hipStream_t s, const FusedParams &p_in, int n
         if (device >= 0 && device < 64) attr_set[device].store(true, std::memory_order_release);
     }
     const int grid = p.n_strips < n_cu ? p.n_strips : n_cu;
+    // static part of the schedule: all but the last two strips of a workgroup's even share,
+    // as far as every list's tickets below n_static * grid / 8 are strips of the array
+    p.n_static = 0;
+    if (grid % 8 == 0 && p.n_strips / grid >= 3) {
+        const int by_share = p.n_strips / grid - 2;
+        const int by_range = (8 * (p.n_strips / 64)) / (grid / 8);
+        p.n_static = by_share < by_range ? by_share : by_range;
+    }
+#ifndef RING_STATIC
+    // (measured: handing out every strip by ticket is faster -- 0.37 against 0.44 ms at
+    // 4096 x 32768 -- although each ticket's wait also waits for the requests in flight:
+    // fixed shares keep the workgroups of an XCD in step, and they then queue on the same
+    // rows; -DRING_STATIC builds the fixed part)
+    p.n_static = 0;
+#endif
+#ifdef RING_TRACE
+    {
+        void *tb = nullptr;
+        KSP_CHECK(hipGetSymbolAddress(&tb, HIP_SYMBOL(ring_trace_buf)));
+        KSP_CHECK(hipMemsetAsync(tb, 0, sizeof(ring_trace_buf), s));
+    }
+#endif
     if (ev0 != nullptr)
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(RING_THREADS), RingLayout::LDS_BYTES, s, ev0, ev1,
                               0, p);
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(RING_THREADS), RingLayout::LDS_BYTES, s, p);
     KSP_LAUNCH_CHECK();
+#ifdef RING_TRACE
+    if (const char *path = getenv("KSP_RING_TRACE")) {
+        KSP_CHECK(hipStreamSynchronize(s));
+        const size_t n = sizeof(ring_trace_buf);
+        void *host = malloc(n);
+        KSP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(ring_trace_buf), n));
+        FILE *f = fopen(path, "wb");
+        if (f != nullptr) {
+            fwrite(host, 1, n, f);
+            fclose(f);
+        }
+        free(host);
+    }
+#endif
     return 0;
 }

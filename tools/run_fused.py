@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
 """Diagnostic: run the fused flagger a few times on the benchmark shape (for rocprofv3).
-Environment: CH, BL (shape), N (launches), FLAGS=NONE|CHANNEL|FULL, RFI=1 (inject interference)."""
+Environment: CH, BL (shape), N (launches), FLAGS=NONE|CHANNEL|FULL, RFI=1 (inject interference),
+PAD (row padding of vis in elements instead of the autotuned one), KSP_LIB (another library build)."""
 import os
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from katsdpsigproc_amd import _lib  # noqa: E402
+
+if os.environ.get("KSP_LIB"):
+    _lib.load(os.path.abspath(os.environ["KSP_LIB"]))
 from katsdpsigproc_amd import accel  # noqa: E402
 from katsdpsigproc_amd.rfi import device  # noqa: E402
 
@@ -19,7 +24,8 @@ t = device.FlaggerDeviceTemplate(
     device.BackgroundMedianFilterDeviceTemplate(ctx, 13, use_flags=device.BackgroundFlags[mode],
                                                 tuning={"csplit": 0}),
     device.NoiseEstMADTDeviceTemplate(ctx, 10240),
-    device.ThresholdSumDeviceTemplate(ctx, tuning={"vt": 0}), fused=True)
+    device.ThresholdSumDeviceTemplate(ctx, tuning={"vt": 0}), fused=True,
+    tuning={"vis_pad": int(os.environ["PAD"])} if "PAD" in os.environ else None)
 fn = t.instantiate(q, channels, baselines, threshold_args={"n_sigma": 11.0})
 fn.ensure_all_bound()
 rs = np.random.RandomState(1)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: time the fused flagger kernel of one library build on the benchmark shape.
 
-    usage: tools/time_fused.py [path/to/lib.so] [NONE|CHANNEL|FULL] [rfi] [dev] [each]
+    usage: [PAD=n] tools/time_fused.py [path/to/lib.so] [NONE|CHANNEL|FULL] [rfi] [dev] [each]
+    (PAD: row padding of vis in elements instead of the autotuned one)
 
 Prints the kernel's mean / min duration (HIP events around the kernel itself) and the
 device time per step (zero-fill + kernel). Input: tiled standard-normal block (cheap to
@@ -32,7 +33,8 @@ use_flags = getattr(device.BackgroundFlags, mode)
 t = device.FlaggerDeviceTemplate(
     device.BackgroundMedianFilterDeviceTemplate(ctx, 13, use_flags=use_flags),
     device.NoiseEstMADTDeviceTemplate(ctx, 16384),
-    device.ThresholdSumDeviceTemplate(ctx), fused=True, keep_deviations="dev" in args)
+    device.ThresholdSumDeviceTemplate(ctx), fused=True, keep_deviations="dev" in args,
+    tuning={"vis_pad": int(os.environ["PAD"])} if "PAD" in os.environ else None)
 fn = t.instantiate(q, channels, baselines, threshold_args={"n_sigma": 11.0})
 fn.ensure_all_bound()
 rs = np.random.RandomState(1)
