@@ -3,8 +3,8 @@
 #include "ksp_common.h"
 
 // 32 x 32 bit-matrix transpose in registers: afterwards a[c] bit i = (old a[i]) bit c.
-// The two coarse stages move whole bytes (v_perm_b32), the three fine ones are the
-// classic masked-swap butterflies.
+// The two coarse stages move whole bytes (v_perm_b32), the three fine ones are masked
+// swaps (a shift and a bit-field insert per register).
 __device__ __forceinline__ void transpose_bits32(unsigned (&a)[32])
 {
 #pragma unroll
@@ -27,9 +27,10 @@ __device__ __forceinline__ void transpose_bits32(unsigned (&a)[32])
 #pragma unroll
         for (int k = 0; k < 32; k++) {
             if (k & j) continue;
-            const unsigned t = ((a[k] >> j) ^ a[k | j]) & m;
-            a[k | j] ^= t;
-            a[k] ^= t << j;
+            // (the masked swap as two bit-field inserts: m << j == ~m for these masks)
+            const unsigned x = a[k], y = a[k | j];
+            a[k] = (x & m) | ((y << j) & ~m);
+            a[k | j] = ((x >> j) & m) | (y & ~m);
         }
     }
 }

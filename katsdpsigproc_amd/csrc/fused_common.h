@@ -599,17 +599,48 @@ __device__ __forceinline__ float ksp_select_dev(const float (&dev)[R], int j)
         return 0.0f;  // (never asked for: HAVE_EXACT needs R == 64)
 }
 
+// The same on float32 bit patterns of non-negative values (they order like the integers),
+// for candidates whose float32 value is the exact one: half the broadcasts and integer
+// compares instead of float64 ones.
+__device__ __forceinline__ void rank_lanes64_u32(unsigned x, int n, int r, int lane, unsigned &xk,
+                                                 unsigned &prev, bool &have_prev)
+{
+    const bool live = lane < n;
+    const unsigned xs = live ? x : 0xffffffffu;  // idle lanes sort last and count nothing below the live ones
+    int cnt = 0;
+#pragma unroll
+    for (int blk = 0; blk < 64; blk += 8) {
+        if (blk >= n) break;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int jj = blk + u;
+            const unsigned y = (unsigned)__builtin_amdgcn_readlane((int)xs, jj);
+            cnt += (y < xs) || (y == xs && jj < lane);
+        }
+    }
+    xk = (unsigned)__builtin_amdgcn_readlane((int)x, __ffsll((long long)ksp_ballot(live && cnt == r)) - 1);
+    have_prev = r >= 1;
+    prev = have_prev ? (unsigned)__builtin_amdgcn_readlane(
+                           (int)x, __ffsll((long long)ksp_ballot(live && cnt == r - 1)) - 1)
+                     : 0u;
+}
+
 // `list` is this wavefront's private candidate list in LDS (LIST_CAP doubles).
 // HAVE_EXACT: the caller knows which deviations are exact as they stand -- bit j of `exact`
 // set means float64(dev[j]) IS the host's float64 deviation of channel c0 + j (a float32
 // difference that did not round, Sterbenz) -- and exact_dev() is then only asked for the
 // others: the usual case needs no amplitude at all.
+// `top_hint` (R == 64, persistent callers): in, the top 8 bits of the key bin the caller's
+// previous baseline ended in, or -1; out, those of this one. The search then first checks,
+// with two wave reductions instead of eight, whether the median lies under the same top
+// bits (neighbouring baselines mostly have noise of the same binade), and only otherwise
+// starts from the top.
 // Returns the float64 noise estimate (NaN when every deviation is zero).
 template <int R, int WIDTH, int LIST_CAP, bool HAVE_EXACT = false, class Fetch>
 __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, double *list,
                                             Fetch &&fetch, int debug_stop = 0,
                                             unsigned long long *trace = nullptr,
-                                            unsigned long long exact = 0)
+                                            unsigned long long exact = 0, int *top_hint = nullptr)
 {
     static_assert(!HAVE_EXACT || R == 64, "exactness masks are 64 bits, one per sample of a lane");
     constexpr int NP = R / 2;
@@ -706,8 +737,42 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             eq1 = take ? (eq1 ^ z1) : z1;
         };
 #if FUSED_MAD_BITS == 1
+        bool hinted = false;
+        if (top_hint != nullptr && *top_hint >= 0) {
+            // follow the hinted top bits down the planes, counting per lane
+            const unsigned h = (unsigned)*top_hint;  // (wave-uniform)
+            unsigned e0 = 0xffffffffu, e1 = 0xffffffffu;
+            int lb = 0;
 #pragma unroll
-        for (int bit = 14; bit >= 0; bit--) step1(bit);
+            for (int bit = 14; bit >= 7; bit--) {
+                const unsigned z0 = e0 & np[bit], z1 = e1 & np[16 + bit];
+                if ((h >> (bit - 7)) & 1) {
+                    lb += __popc(z0) + __popc(z1);
+                    e0 ^= z0;
+                    e1 ^= z1;
+                } else {
+                    e0 = z0;
+                    e1 = z1;
+                }
+            }
+            int cnt = __popc(e0) + __popc(e1);
+            ksp_wave_sum2_dpp(lb, cnt);
+            if (lb <= rank && rank < lb + cnt) {
+                hinted = true;
+                K = h << 7;
+                below_bin = lb;
+                eq0 = e0;
+                eq1 = e1;
+            }
+        }
+        if (hinted) {
+#pragma unroll
+            for (int bit = 6; bit >= 0; bit--) step1(bit);
+        } else {
+#pragma unroll
+            for (int bit = 14; bit >= 0; bit--) step1(bit);
+        }
+        if (top_hint != nullptr) *top_hint = (int)(K >> 7);
 #else
 #pragma unroll
         for (int bit = 14; bit >= 2; bit -= 2) step2(bit, bit - 1);
@@ -875,6 +940,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             n += __popcll(m);
         };
         double x;
+        bool ranked = false;
         if constexpr (R == 64 && HAVE_EXACT) {
             // every lane knows its own hits (eq0 / eq1): it hands out channel, exactness and
             // |float32 deviation| of each (the deviation through ksp_select64: as many rounds
@@ -905,13 +971,21 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             __builtin_amdgcn_wave_barrier();
             const int slot = lane < n ? lane : 0;
             const int e0 = lc[2 * slot];
-            x = (double)__int_as_float(lc[2 * slot + 1]);
+            const unsigned a32 = (unsigned)lc[2 * slot + 1];
+            x = (double)__uint_as_float(a32);
             const bool inexact = lane < n && e0 >= 0;
             stamp(11);
             if (debug_stop == 33) return x;
             if (ksp_any(inexact)) {
                 const double xe = fabs(exact_dev<WIDTH>(e0 & 0x7fffffff, fetch));
                 x = inexact ? xe : x;
+            } else {
+                // every candidate's float32 value is the exact one: rank those
+                unsigned k32, p32;
+                rank_lanes64_u32(a32, n, r, lane, k32, p32, have_prev);
+                xk = (double)__uint_as_float(k32);
+                prev = (double)__uint_as_float(p32);
+                ranked = true;
             }
         } else {
             if constexpr (R == 64) {
@@ -945,7 +1019,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             x = fabs(exact_dev<WIDTH>(c, fetch));
         }
         stamp(12);
-        rank_lanes64(x, n, r, lane, xk, prev, have_prev);
+        if (!ranked) rank_lanes64(x, n, r, lane, xk, prev, have_prev);
         stamp(13);
         __builtin_amdgcn_wave_barrier();
     } else {

@@ -41,6 +41,9 @@
 #ifndef RING_G
 #define RING_G 4                 // steps per chunk
 #endif
+#ifndef RING_PRIO
+#define RING_PRIO 0  // experiments with s_setprio between the two wavefronts of a SIMD
+#endif
 #ifndef RING_STAGGER
 #define RING_STAGGER 0           // x 8128 cycles: every other workgroup of an XCD starts late (diagnostic)
 #endif
@@ -203,13 +206,28 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);  // (the builtin returns int)
     };
     run_src = start_of(cur);
-    // (steps NSLOT - G .. NSLOT - 1 are requested behind the first barrier, as for every
-    // later strip)
 #pragma unroll
-    for (int j = 0; j < NSLOT - G; j += 2) issue(j);
+    for (int j = 0; j < NSLOT; j += 2) issue(j);
+    // Two register sets of raw samples: a chunk is read from the ring while the one before
+    // it is worked on. Chunk 0 of the first strip:
+    float2 zz[2][G];
+    {
+        constexpr int AH0 = (K - 1) * PER_CHUNK;
+        __builtin_amdgcn_s_waitcnt(0x0070 | (AH0 & 15) | ((AH0 >> 4) << 14));
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const unsigned long long w = *(lds_cu64 *)(lds3 + rd_off + g * RING_SLOT_BYTES);
+            zz[0][g] = make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+        }
+    }
     const float nanv = __builtin_nanf("");
     const float2 *visf = (const float2 *)p.vis;
 
+#if RING_PRIO == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    int mad_hint = -1;  // top bits of the previous strip's MAD key bin (fused_common.h, mad_noise)
     const int lane_id = lane;
 #ifdef RING_TRACE
     int trace_it = 0;
@@ -254,14 +272,17 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         // chunk c: make its 4 steps visible, refill the previous chunk's slots, |z|
         auto load_chunk = [&](auto c_) {
             constexpr int c = decltype(c_)::value;
-            // this wavefront's pieces of chunk c have landed: it has issued those of chunks
-            // c + 1 .. c + K - 2 after them (the last strip stops at its own last chunk)
+            // Chunk c sits in registers (read during chunk c - 1). Before anything of it is
+            // used: this wavefront's pieces of chunk c + 1 have landed -- it has issued those
+            // of chunks c + 2 .. c + K - 1 after them (the last strip stops at its own last
+            // chunk) -- and its reads of chunk c have returned; behind the barrier that holds
+            // for every wavefront.
             constexpr int AH = (K - 2) * PER_CHUNK;
 #ifdef RING_TRACE
             unsigned long long w0;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0));
 #endif
-            if (more || (c + K - 2) * G + G <= STEPS)
+            if (more || (c + K - 1) * G + G <= STEPS)
                 __builtin_amdgcn_s_waitcnt(0x0070 | (AH & 15) | ((AH >> 4) << 14));
             else
                 __builtin_amdgcn_s_waitcnt(0x0070);
@@ -269,18 +290,19 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
             unsigned long long w1;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1));
 #endif
+#ifndef RING_NOSYNC  // (diagnostic: what do the barriers cost? results are then wrong)
             __syncthreads();
+#endif
 #ifdef RING_TRACE
             unsigned long long w2;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w2));
             wait_dma += w1 - w0;
             wait_bar += w2 - w1;
 #endif
-            // the slots of chunk c - 1 (every wavefront has read them) take the steps
-            // NSLOT further on; chunk -1 = the previous strip's last chunk
+            // the slots of chunk c take the steps NSLOT further on (of the next strip from
+            // chunk NCHUNK - K on)
             ksp_static_for<G / 2>([&](auto u_) {
-                constexpr int cm = (c + NCHUNK - 1) % NCHUNK;
-                constexpr int j = cm * G + 2 * decltype(u_)::value + NSLOT - (c == 0 ? STEPS : 0);
+                constexpr int j = c * G + 2 * decltype(u_)::value + NSLOT;
                 if constexpr (j < STEPS) {
                     issue(j % NSLOT);
                 } else if (more) {
@@ -288,14 +310,25 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                     issue(j % NSLOT);
                 }
             });
-            float2 z[G];
-            unsigned ro = rd_off;
-            asm volatile("" : "+v"(ro));  // (opaque: or 16 slot addresses are kept in registers for good)
+            // chunk c + 1 into the other register set (chunk 0 of the next strip at the end)
+            if (c + 1 < NCHUNK || more) {
+                // (one address per chunk, opaque: or the compiler keeps 16 slot addresses in
+                // registers for good, or adds the slot offset once per read)
+                unsigned ro = rd_off + (((c + 1) * G) % NSLOT) * RING_SLOT_BYTES;
+                asm volatile("" : "+v"(ro));
 #pragma unroll
-            for (int g = 0; g < G; g++) {
-                const unsigned long long w = *(lds_cu64 *)(lds3 + ro + ((c * G + g) % NSLOT) * RING_SLOT_BYTES);
-                z[g] = make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+                for (int g = 0; g < G; g++) {
+                    const unsigned long long w = *(lds_cu64 *)(lds3 + ro + g * RING_SLOT_BYTES);
+                    zz[(c + 1) & 1][g] = make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+                }
             }
+#if RING_PRIO == 2
+            if ((c + (wave >> 2)) & 1)
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            const float2 (&z)[G] = zz[c & 1];
             // |z| (numpy's; packed short division when every magnitude is ordinary)
             unsigned key = ~0u;
 #pragma unroll
@@ -413,7 +446,11 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                             note_exact(ex_a, xc, med, d);
                         else
                             note_exact(ex_b, xc, med, d);
-                        dmax = mm.vmax(dmax, d);
+                        // (the running maximum takes two outputs at a time)
+                        if constexpr (jv & 1)
+                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(dmax) : "v"(dev[j - 1]), "v"(d));
+                        else if constexpr (jv == RV - 1)
+                            dmax = mm.vmax(dmax, d);
                         dev[j] = d;
                     }
                 });
@@ -526,7 +563,7 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         }
 #else
         const double noise64 = mad_noise<R, W, RING_LIST_DOUBLES, true>(dev, lane, list, fetch, RING_STOP > 30 ? RING_STOP : 0,
-                                                                      nullptr, exact);
+                                                                      nullptr, exact, &mad_hint);
         if (lane == 0 && p.noise != nullptr) p.noise[bl] = (float)noise64;
         RING_STAMP(2);
 #if RING_STOP == 3 || RING_STOP > 30
