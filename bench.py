@@ -78,6 +78,30 @@ def host_cores() -> int:
         return os.cpu_count() or 1
 
 
+def numpy_baseline():
+    """The NumPy restatement of the reference's host path (katsdpsigproc_amd.rfi.host, checked
+    against the golden vectors of the imported reference) on BASELINE.json config 1, the shape
+    scripts/rfiflagtest.py times on the host: 1024 channels x 2048 baselines, one warm-up call,
+    one timed call, one core."""
+    from katsdpsigproc_amd.rfi import host
+
+    channels, baselines = 1024, 2048
+    vis = synth_block(channels, baselines, 1)
+    flagger = host.FlaggerHost(host.BackgroundMedianFilterHost(WIDTH), host.NoiseEstMADHost(),
+                               host.ThresholdSumHost(N_SIGMA))  # fmt: skip
+    flagger(vis[:, :64])  # warm-up (imports, allocator)
+    t0 = time.perf_counter()
+    flagger(vis)
+    dt = time.perf_counter() - t0
+    return {
+        "value": channels * baselines / dt,
+        "unit": "samples/s",
+        "cores": 1,
+        "kind": "numpy",
+        "sample": f"{channels} ch x {baselines} bl complex64 (BASELINE config 1), one call, {dt:.2f} s",
+    }
+
+
 def cpu_baseline(budget_s: float = 20.0):
     """Time the oracle (C restatement of rfi.host.FlaggerHost) on one core.
 
@@ -103,22 +127,31 @@ def cpu_baseline(budget_s: float = 20.0):
         dt = time.perf_counter() - t0
     samples = CHANNELS * baselines
     single = samples / dt
-    # all cores, for context (OpenMP over baselines)
-    oracle.set_threads(threads)
-    t0 = time.perf_counter()
-    oracle.flagger_full(vis, width=WIDTH, n_sigma=N_SIGMA)
-    dt_all = time.perf_counter() - t0
-    oracle.set_threads(1)
-    return {
+    dt_all = dt
+    if threads > 1:
+        # all cores this process may use, for context (OpenMP over baselines)
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        oracle.flagger_full(vis, width=WIDTH, n_sigma=N_SIGMA)
+        dt_all = time.perf_counter() - t0
+        oracle.set_threads(1)
+    out = {
         "value": single,
         "unit": "samples/s",
         "cores": 1,
         "kind": "port",
         "sample": f"{CHANNELS} ch x {baselines} bl complex64, one call, {dt:.2f} s",
-        "all_cores_value": samples / dt_all,
-        "all_cores": threads,
         "host_cpus": os.cpu_count(),
+        "affinity_cores": host_cores(),  # what this process may run on (sched_getaffinity)
     }
+    if threads > 1:  # (a process confined to one core has no all-cores figure)
+        out["all_cores_value"] = samples / dt_all
+        out["all_cores"] = threads
+    try:
+        out["numpy_path"] = numpy_baseline()
+    except Exception as exc:  # the headline must not depend on it
+        out["numpy_path"] = {"error": repr(exc)}
+    return out
 
 
 def check_against_oracle(vis_slice, mask, flags_slice, noise_slice) -> dict:
@@ -240,10 +273,19 @@ def bringup_configs(context, queue, vis_host) -> dict:
     from katsdpsigproc_amd import percentile, transpose
     from katsdpsigproc_amd.rfi import device
 
-    def entry(seconds, nbytes, note):
+    from oracle import rfi_oracle as oracle  # the checker of each leg's output, never timed
+
+    def entry(seconds, nbytes, note, checked):
         gbs = nbytes / seconds / 1e9
         return {"ms": 1e3 * seconds, "algorithmic_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes": note}  # fmt: skip
+                "algorithmic_bytes": note, "output_checked": checked}  # fmt: skip
+
+    def must(ok: bool, what: str) -> str:
+        if not ok:
+            raise SystemExit(f"bench.py: bring-up leg differs from its reference: {what}")
+        return what
+
+    SL = 64  # baselines (or rows) of each leg's output compared with the oracle / NumPy
 
     out = {}
     n = 4096
@@ -252,19 +294,31 @@ def bringup_configs(context, queue, vis_host) -> dict:
     op = transpose.TransposeTemplate(context, np.float32, "float").instantiate(queue, (n, n))
     op.ensure_all_bound()
     op.buffer("src").set(queue, src)
-    out["config2_transpose_4096x4096_f32"] = entry(time_op(queue, op), 8 * n * n, "8 B/element")
+    seconds = time_op(queue, op)
+    out["config2_transpose_4096x4096_f32"] = entry(
+        seconds, 8 * n * n, "8 B/element",
+        must(np.array_equal(op.buffer("dest").get(queue), src.T), "whole output == src.T"))
     op = percentile.Percentile5Template(context, n, is_amplitude=True).instantiate(queue, (n, n))
     op.ensure_all_bound()
     op.buffer("src").set(queue, src)
-    out["config2_percentile5_4096x4096_f32"] = entry(time_op(queue, op), 4 * n * n, "4 B/element")
+    seconds = time_op(queue, op)
+    out["config2_percentile5_4096x4096_f32"] = entry(
+        seconds, 4 * n * n, "4 B/element",
+        must(np.array_equal(op.buffer("dest").get(queue), oracle.percentile5(src)),
+             "whole output == oracle.percentile5 (NumPy 'lower' percentiles)"))
     del op
     C, B = 4096, 8192
     block = np.ascontiguousarray(vis_host[:, :B])
     bg = device.BackgroundMedianFilterDeviceTemplate(context, WIDTH).instantiate(queue, C, B)
     bg.ensure_all_bound()
     bg.buffer("vis").set(queue, block)
-    out["config3_background_4096x8192_c64"] = entry(time_op(queue, bg), 12 * C * B, "12 B/sample")
+    seconds = time_op(queue, bg)
     dev = bg.buffer("deviations").get(queue)
+    ref_dev = oracle.BackgroundMedianFilterHost(WIDTH)(block[:, :SL])
+    out["config3_background_4096x8192_c64"] = entry(
+        seconds, 12 * C * B, "12 B/sample",
+        must(np.array_equal(dev[:, :SL], ref_dev.astype(np.float32)),
+             f"first {SL} baselines == float32(oracle deviations)"))
     for name, tmpl in (
         ("config3_noise_mad_4096x8192", device.NoiseEstMADDeviceTemplate(context)),
         ("config3_noise_mad_t_4096x8192", device.NoiseEstMADTDeviceTemplate(context, 10240)),
@@ -272,7 +326,12 @@ def bringup_configs(context, queue, vis_host) -> dict:
         ne = tmpl.instantiate(queue, C, B)
         ne.ensure_all_bound()
         ne.buffer("deviations").set(queue, np.ascontiguousarray(dev.T) if tmpl.transposed else dev)
-        out[name] = entry(time_op(queue, ne), 4 * C * B, "4 B/sample")
+        seconds = time_op(queue, ne)
+        ref_noise = oracle.NoiseEstMADHost()(np.ascontiguousarray(dev[:, :SL]))
+        out[name] = entry(
+            seconds, 4 * C * B, "4 B/sample",
+            must(np.array_equal(ne.buffer("noise").get(queue)[:SL], ref_noise.astype(np.float32)),
+                 f"first {SL} baselines == float32(oracle MAD of the float32 deviations)"))
     del dev, bg, ne
     # the reference-shaped five-kernel sequence and the fused kernel on config 3's block
     for fused in (False, True):
@@ -286,7 +345,12 @@ def bringup_configs(context, queue, vis_host) -> dict:
         fn.ensure_all_bound()
         fn.buffer("vis").set(queue, block)
         key = "flagger_fused_4096x8192" if fused else "flagger_sequence_5_kernels_4096x8192"
-        out[key] = entry(time_op(queue, fn), 9 * C * B, "9 B/sample")
+        seconds = time_op(queue, fn)
+        ref_flags, _ = oracle.flagger_full(block[:, :SL], width=WIDTH, n_sigma=N_SIGMA)
+        out[key] = entry(
+            seconds, 9 * C * B, "9 B/sample",
+            must(np.array_equal(fn.buffer("flags").get(queue)[:, :SL], ref_flags),
+                 f"flags of the first {SL} baselines == oracle"))
     del fn
     # the reference script's wider presets (scripts/rfiflagtest.py:190-195): the same
     # number of samples laid out as 8192 and 10240 channels (fused long-band kernels)
@@ -303,8 +367,12 @@ def bringup_configs(context, queue, vis_host) -> dict:
         fn = template.instantiate(queue, channels, baselines, threshold_args={"n_sigma": N_SIGMA})
         fn.ensure_all_bound()
         fn.buffer("vis").set(queue, long_block)
+        seconds = time_op(queue, fn)
+        ref_flags, _ = oracle.flagger_full(long_block[:, :SL], width=WIDTH, n_sigma=N_SIGMA)
         out[f"flagger_fused_{channels}x{baselines}"] = entry(
-            time_op(queue, fn), 9 * channels * baselines, "9 B/sample")
+            seconds, 9 * channels * baselines, "9 B/sample",
+            must(np.array_equal(fn.buffer("flags").get(queue)[:, :SL], ref_flags),
+                 f"flags of the first {SL} baselines == oracle"))
     return out
 
 
@@ -420,7 +488,10 @@ def main() -> int:
         }
         with torch.cuda.stream(comm):
             dist.broadcast(pipe["tensors"][0], src=0)
-        pipe["ready"][0] = pipe["comm_queue"].enqueue_marker(ordering_only=True)
+        # (the "ready" edge follows a broadcast, i.e. possibly a peer's writes over xGMI: a
+        # normal event, whose record flushes; the "free" edge orders a local kernel before
+        # a later broadcast and needs no more than ordering)
+        pipe["ready"][0] = pipe["comm_queue"].enqueue_marker()
         pipe["free"][1] = queue.enqueue_marker(ordering_only=True)
 
     def step() -> None:
@@ -437,7 +508,7 @@ def main() -> int:
         pipe["comm_queue"].enqueue_wait_for_events([pipe["free"][j]])  # the kernel that last read buffer j
         with torch.cuda.stream(pipe["comm"]):
             dist.broadcast(pipe["tensors"][j], src=0)
-        pipe["ready"][j] = pipe["comm_queue"].enqueue_marker(ordering_only=True)
+        pipe["ready"][j] = pipe["comm_queue"].enqueue_marker()
 
     def sync() -> None:
         queue.finish()
@@ -486,6 +557,17 @@ def main() -> int:
     # clocks (launches right after set-up run up to 15 % longer). A continuously fed
     # flagger lives in the sustained state, so that is what the timed region measures;
     # the first launches are reported beside it as `cold_start`.
+    # the reference script's own method (scripts/rfiflagtest.py:88-107): one warm-up call,
+    # then repeats timed one by one, from an idle device -- median of 10
+    single_shot = None
+    if args.preheat > 0 and pipe is None:
+        step()
+        sync()
+        s_step, _ = sampled(10)
+        single_shot = {"method": "one warm-up call, then 10 calls timed one by one from idle (median)",
+                       "step_device_ms": 1e3 * float(np.median(s_step)),
+                       "frac": channels * baselines * (ALGORITHMIC_BYTES_PER_SAMPLE + (4 if args.keep_deviations else 0))
+                               / float(np.median(s_step)) / 1e9 / HBM_PEAK_GBS}  # fmt: skip
     cold = None
     if args.preheat > 0:
         n_cold = min(20, args.preheat)
@@ -517,6 +599,13 @@ def main() -> int:
         )  # fmt: skip
         verified["flagged_fraction_of_block"] = float(np.count_nonzero(flags_out)) / flags_out.size
         del flags_out
+        if pipe is not None:
+            # every rank: both mask buffers hold what rank 0 broadcast
+            got = [b.get(queue) for b in pipe["bufs"]]
+            ok = all(np.array_equal(g, mask) for g in got)
+            if not ok:
+                raise SystemExit(f"bench.py: rank {rank}: a broadcast channel mask differs from rank 0's")
+            verified["mask_buffers_equal_on_rank"] = rank
 
     samples_per_gpu = channels * baselines
     n_bytes = ALGORITHMIC_BYTES_PER_SAMPLE + (4 if args.keep_deviations else 0)
@@ -555,7 +644,8 @@ def main() -> int:
             "roofline": {
                 "bound": "hbm",
                 "kernel": "sequence" if args.sequence
-                          else "flagger_fused_kernel + zero-fill of flags (one step)",
+                          else "flagger_ring_kernel (persistent, 8-baseline strips) + zero-fill of"
+                               " flags (one step)",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "GB/s",
@@ -573,7 +663,10 @@ def main() -> int:
                 },
                 "frac_kernel_only": samples_per_gpu * n_bytes / kernel_mean / 1e9 / HBM_PEAK_GBS,
                 "traffic": measured_traffic(channels, baselines, use_flags.name, args),
+                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of the same launch,"
+                                  " tools/pmc_mem.sh; not read in this run)",
                 "cold_start": cold,
+                "single_shot": single_shot,
             },
             "verified": verified,
         }  # fmt: skip

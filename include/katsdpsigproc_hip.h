@@ -188,6 +188,15 @@ int ksp_flagger_fused_profile(void *start_event, void *stop_event);
  * back to the kernel-per-stage sequence). */
 int ksp_flagger_fused_supported(int channels, int width, int n_windows);
 
+/* Which kernels the calling thread's LAST ksp_flagger_fused call launched (no reference
+ * counterpart: the tests use it to prove which path they exercised): 0 none, or a sum of
+ * 1 = flagger_fused_kernel (strips of 4 baselines, up to 4096 channels),
+ * 2 = flagger_long_kernel (4097-12288 channels),
+ * 4 = flagger_ring_kernel (persistent, strips of 8 baselines, 4096 channels, complex input
+ *     without input flags, no deviations output); 5 = ring kernel plus the 4-baseline kernel
+ *     for a remainder of fewer than 8 baselines. */
+int ksp_flagger_fused_last_path(void);
+
 /* Self-tests of the arithmetic building blocks (no reference counterpart; they exist
  * so that the test-suite can pin device arithmetic against IEEE / numpy results).
  * ksp_selftest_sqrt12: out[i] = the kernels' square root of the float32 with bit

@@ -94,6 +94,7 @@ SIGNATURES = {
         c_int, c_void_p,
     ],
     "ksp_flagger_fused_supported": [c_int, c_int, c_int],
+    "ksp_flagger_fused_last_path": [],
     "ksp_rtc_compile": [
         c_int, c_char_p, POINTER(c_char_p), c_int, POINTER(c_void_p), c_char_p, c_size_t
     ],
@@ -118,7 +119,7 @@ _OTHER = {
 }
 
 #: functions whose int return value is a result, not an error code
-_VALUE_RETURN = {"ksp_flagger_fused_supported"}
+_VALUE_RETURN = {"ksp_flagger_fused_supported", "ksp_flagger_fused_last_path"}
 
 
 def declared_symbols():

@@ -30,6 +30,8 @@
 
 // Events armed by ksp_flagger_fused_profile for the NEXT fused launch of this thread.
 static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+// Kernels launched by this thread's last ksp_flagger_fused call (ksp_flagger_fused_last_path).
+static thread_local int g_last_path = 0;
 
 // widths other than 13 (flagger_fused_w*.hip): lanes always own 64 channels there
 int ksp_fused_launch_w3_7(int width, int device, hipStream_t s, const FusedParams &p,
@@ -68,6 +70,8 @@ extern "C" int ksp_flagger_fused_profile(void *start_event, void *stop_event)
     return 0;
 }
 
+extern "C" int ksp_flagger_fused_last_path(void) { return g_last_path; }
+
 extern "C" int ksp_flagger_fused_supported(int channels, int width, int n_windows)
 {
     if (n_windows < 1 || n_windows > 4) return 0;
@@ -86,6 +90,7 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     // profiling events are consumed by this call whatever its outcome
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
+    g_last_path = 0;
     KSP_REQUIRE(vis != nullptr && flags != nullptr, "NULL buffer");
     KSP_REQUIRE(channels >= 1 && baselines >= 0, "bad shape");
     KSP_REQUIRE(vis_stride >= baselines && flags_stride >= baselines, "stride smaller than row");
@@ -173,9 +178,12 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
             t.dyn_blocks = 0;
             const int rc = launch_fused<64, 13>(device, s, t, nullptr, nullptr, false);
             if (rc != 0) return rc;
+            g_last_path |= 1;
         }
+        g_last_path |= 4;
         return ksp_ring_launch(width, device, s, p, n_cu, ev0, ev1);
     }
+    g_last_path = channels > 4096 ? 2 : 1;
     if (channels > 4096) return ksp_fused_launch_long(device, s, p, ev0, ev1);
     if (width != 13) return ksp_fused_launch_other_width(width, device, s, p, ev0, ev1);
     if (channels <= 64 * 4) return launch_fused<4, 13>(device, s, p, ev0, ev1);

@@ -80,7 +80,37 @@ def run_fused(template, command_queue, vis, in_flags=None, **threshold_args):
            "noise": fn.buffer("noise").get(command_queue)}  # fmt: skip
     if "deviations" in fn.slots:
         out["deviations"] = fn.buffer("deviations").get(command_queue)
+    check_ring_path(template, command_queue, vis, in_flags, threshold_args, out)
     return out
+
+
+def check_ring_path(template, command_queue, vis, in_flags, threshold_args, out):
+    """Launches that keep the deviations take the 4-baseline kernel; without them a
+    4096-channel launch of complex visibilities without input flags (width 13, at least 8
+    baselines) takes the persistent ring kernel. Every parity test of such a shape therefore
+    runs it as well: same flags, same noise as the run the test compares with the oracle,
+    and ksp_flagger_fused_last_path says the ring kernel did it."""
+    from katsdpsigproc_amd import _lib
+    from katsdpsigproc_amd.rfi import device
+
+    bg = template.background
+    if not (vis.shape[0] == 4096 and vis.shape[1] >= 8 and in_flags is None
+            and np.iscomplexobj(vis) and bg.width == 13 and not bg.is_amplitude
+            and "deviations" in out):  # fmt: skip
+        return
+    lean = device.FlaggerDeviceTemplate(bg, template.noise_est, template.threshold, fused=True,
+                                        keep_deviations=False, tuning=template._fused_tuning)  # fmt: skip
+    fn = lean.instantiate(command_queue, vis.shape[0], vis.shape[1], threshold_args=threshold_args)
+    fn.ensure_all_bound()
+    fn.buffer("vis").set(command_queue, vis)
+    for _ in range(2):  # (twice: the scheduling counters must be left as they were found)
+        fn.buffer("flags").set(command_queue, np.full(vis.shape, 255, np.uint8))
+        fn()
+        path = _lib.call("ksp_flagger_fused_last_path")
+        assert path & 4, f"expected the ring kernel, last path = {path}"
+        assert (path & 1) == (1 if vis.shape[1] % 8 else 0)
+        np.testing.assert_array_equal(fn.buffer("flags").get(command_queue), out["flags"])
+        np.testing.assert_array_equal(fn.buffer("noise").get(command_queue), out["noise"])
 
 
 class TestSequence:
