@@ -599,29 +599,36 @@ __device__ __forceinline__ float ksp_select_dev(const float (&dev)[R], int j)
         return 0.0f;  // (never asked for: HAVE_EXACT needs R == 64)
 }
 
-// The same on float32 bit patterns of non-negative values (they order like the integers),
-// for candidates whose float32 value is the exact one: half the broadcasts and integer
-// compares instead of float64 ones.
-__device__ __forceinline__ void rank_lanes64_u32(unsigned x, int n, int r, int lane, unsigned &xk,
-                                                 unsigned &prev, bool &have_prev)
+// Ranking of candidates whose float32 value is the exact one, on the bit patterns (non-negative
+// floats order like the integers).
+__device__ __forceinline__ void rank_list_u32(const unsigned *vals, unsigned x, int n, int r,
+                                              int lane, unsigned &xk, unsigned &prev,
+                                              bool &have_prev)
 {
+    // `vals` (LDS, 16-byte aligned, n <= 64 entries, padded with 0xffffffff to a multiple of
+    // 4) holds every candidate; each lane compares its own x with all of them -- broadcast
+    // reads and independent compares instead of a chain of lane broadcasts through scalar
+    // registers. Equal values are interchangeable (equal float32 values that are exact are
+    // equal exact values), so the value of rank k is held by any lane with
+    // #(values < x) <= k < #(values <= x).
     const bool live = lane < n;
-    const unsigned xs = live ? x : 0xffffffffu;  // idle lanes sort last and count nothing below the live ones
-    int cnt = 0;
+    int lt = 0, le = 0;
 #pragma unroll
     for (int blk = 0; blk < 64; blk += 8) {
         if (blk >= n) break;
+        const uint4 a = *(const uint4 *)(vals + blk), b = *(const uint4 *)(vals + blk + 4);
+        const unsigned y[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int jj = blk + u;
-            const unsigned y = (unsigned)__builtin_amdgcn_readlane((int)xs, jj);
-            cnt += (y < xs) || (y == xs && jj < lane);
+            lt += y[u] < x;
+            le += y[u] <= x;
         }
     }
-    xk = (unsigned)__builtin_amdgcn_readlane((int)x, __ffsll((long long)ksp_ballot(live && cnt == r)) - 1);
+    xk = (unsigned)__builtin_amdgcn_readlane(
+        (int)x, __ffsll((long long)ksp_ballot(live && lt <= r && r < le)) - 1);
     have_prev = r >= 1;
     prev = have_prev ? (unsigned)__builtin_amdgcn_readlane(
-                           (int)x, __ffsll((long long)ksp_ballot(live && cnt == r - 1)) - 1)
+                           (int)x, __ffsll((long long)ksp_ballot(live && lt <= r - 1 && r - 1 < le)) - 1)
                      : 0u;
 }
 
@@ -766,6 +773,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             }
         }
         if (hinted) {
+            // (two bits per step measure 1-2 % slower here as well)
 #pragma unroll
             for (int bit = 6; bit >= 0; bit--) step1(bit);
         } else {
@@ -941,6 +949,8 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         };
         double x;
         bool ranked = false;
+        unsigned *lv = (unsigned *)lc + 128;  // HAVE_EXACT: |float32 deviations| of the candidates
+        static_assert(LIST_CAP * 2 >= 128 + 64 + 8, "candidate values behind the channel numbers");
         if constexpr (R == 64 && HAVE_EXACT) {
             // every lane knows its own hits (eq0 / eq1): it hands out channel, exactness and
             // |float32 deviation| of each (the deviation through ksp_select64: as many rounds
@@ -962,16 +972,18 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
                 }
                 const float v = ksp_select_dev<R>(dev, j);
                 if (has) {
-                    lc[2 * pos] = (c0 + j) | (((exact >> j) & 1) ? (int)0x80000000 : 0);
-                    lc[2 * pos + 1] = (int)(__float_as_uint(v) & 0x7fffffffu);
+                    lc[pos] = (c0 + j) | (((exact >> j) & 1) ? (int)0x80000000 : 0);
+                    lv[pos] = __float_as_uint(v) & 0x7fffffffu;
                     pos++;
                 }
             }
+            // (padding for the 8 values at a time that the ranking reads)
+            if (lane < 8) lv[n + lane] = 0xffffffffu;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int slot = lane < n ? lane : 0;
-            const int e0 = lc[2 * slot];
-            const unsigned a32 = (unsigned)lc[2 * slot + 1];
+            const int e0 = lc[slot];
+            const unsigned a32 = lv[slot];
             x = (double)__uint_as_float(a32);
             const bool inexact = lane < n && e0 >= 0;
             stamp(11);
@@ -982,7 +994,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             } else {
                 // every candidate's float32 value is the exact one: rank those
                 unsigned k32, p32;
-                rank_lanes64_u32(a32, n, r, lane, k32, p32, have_prev);
+                rank_list_u32(lv, a32, n, r, lane, k32, p32, have_prev);
                 xk = (double)__uint_as_float(k32);
                 prev = (double)__uint_as_float(p32);
                 ranked = true;

@@ -62,7 +62,8 @@ struct RingLayout {
 // diagnostic builds (-DRING_TRACE): shader-clock stamps [workgroup][wavefront][strip][8],
 // dumped by launch_ring to the file named by KSP_RING_TRACE (tools/trace_ring.py)
 #define RING_TRACE_STRIPS 24
-__device__ unsigned long long ring_trace_buf[256 * 8 * RING_TRACE_STRIPS * 8];
+#define RING_TRACE_SLOTS 16
+__device__ unsigned long long ring_trace_buf[256 * 8 * RING_TRACE_STRIPS * RING_TRACE_SLOTS];
 #endif
 
 // workspace words used by this kernel (the 4-baseline kernels use [0], [1])
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
 #define RING_STAMP(i)                                                                              \
     do {                                                                                           \
         if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256)                      \
-            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + (i)] =   \
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * RING_TRACE_SLOTS + (i)] =   \
                 __builtin_amdgcn_s_memtime();                                                      \
     } while (0)
 #else
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
 #ifdef RING_TRACE
         unsigned long long wait_dma = 0, wait_bar = 0;
         if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256)
-            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * RING_TRACE_SLOTS + 4] = __builtin_amdgcn_s_memrealtime();
 #endif
         float amp[STEPS];
         unsigned umax = 0;
@@ -512,8 +513,8 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         RING_STAMP(1);
 #ifdef RING_TRACE
         if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256) {
-            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 5] = wait_dma;
-            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 6] = wait_bar;
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * RING_TRACE_SLOTS + 5] = wait_dma;
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * RING_TRACE_SLOTS + 6] = wait_bar;
         }
 #endif
         // bit j of `exact`: output j. ex_a holds outputs H .. H + 31 (the first at bit 31),
@@ -563,7 +564,14 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         }
 #else
         const double noise64 = mad_noise<R, W, RING_LIST_DOUBLES, true>(dev, lane, list, fetch, RING_STOP > 30 ? RING_STOP : 0,
-                                                                      nullptr, exact, &mad_hint);
+#ifdef RING_TRACE
+                                                                      (trace_it < RING_TRACE_STRIPS && blockIdx.x < 256)
+                                                                          ? &ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * RING_TRACE_SLOTS]
+                                                                          : nullptr,
+#else
+                                                                      nullptr,
+#endif
+                                                                      exact, &mad_hint);
         if (lane == 0 && p.noise != nullptr) p.noise[bl] = (float)noise64;
         RING_STAMP(2);
 #if RING_STOP == 3 || RING_STOP > 30
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
 
 #ifdef RING_TRACE
         if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256)
-            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * 8 + 7] = (unsigned long long)cur + 1;
+            ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * RING_TRACE_SLOTS + 7] = (unsigned long long)cur + 1;
         trace_it++;
 #endif
         if (!more) break;

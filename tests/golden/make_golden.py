@@ -83,6 +83,16 @@ def main() -> None:
     fl = th(dev_t, noise32)
     assert set(np.unique(fl)) <= {0, 4}
     out["threshold_sum_f32_params"] = np.packbits(fl.astype(np.bool_))
+    # 6 and 8 windows (sums of 32 and 128 terms, which numpy.convolve does not promise to
+    # add left to right): float32 and float64 deviations with broad interference added, so
+    # that the wide windows decide flags the narrow ones do not
+    wide32, wide_noise32 = inputs.threshold_wide_case()
+    wide64 = wide32.astype(np.float64) * 1.0000001
+    wide_noise64 = wide_noise32.astype(np.float64) * 1.0000003
+    for n_windows in (6, 8):
+        th = host.ThresholdSumHost(6.0, n_windows=n_windows)
+        out[f"threshold_sum_f32_w{n_windows}"] = np.packbits(th(wide32, wide_noise32).astype(np.bool_))
+        out[f"threshold_sum_f64_w{n_windows}"] = np.packbits(th(wide64, wide_noise64).astype(np.bool_))
 
     # (ii-d) flagger 117x131 with injected RFI, three flag modes, Simple and Sum
     vis_f, _sp, in_flags = inputs.flagger_case()

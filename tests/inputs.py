@@ -129,3 +129,21 @@ def add_rfi_sparse(vis, seed=3, fraction=1.0 / 16.0, block=256):
         phase = rs.random_sample(n) * (2.0 * np.pi)
         part[hit] += (amp * np.exp(1j * phase)).astype(np.complex64)
     return vis
+
+
+def threshold_wide_case(seed=11):
+    """Deviations for SumThreshold with 6 and 8 windows: 273 channels x 117 baselines of
+    unit noise (float32) with runs of 3..40 channels raised by 2.5..6 (broad, weak
+    interference that only the wide windows can find) and a few strong spikes; noise
+    estimates near 1. Returns (deviations [C][B] float32, noise [B] float32)."""
+    rs = np.random.RandomState(seed)
+    channels, baselines = 273, 117
+    dev = rs.standard_normal((channels, baselines)).astype(np.float32)
+    for b in range(baselines):
+        for _ in range(3):
+            start = rs.randint(0, channels - 40)
+            length = rs.randint(3, 41)
+            dev[start : start + length, b] += np.float32(2.5 + 3.5 * rs.random_sample())
+        dev[rs.randint(0, channels, 2), b] += 40.0
+    noise = (0.9 + 0.2 * rs.random_sample(baselines)).astype(np.float32)
+    return dev, noise

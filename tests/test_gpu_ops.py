@@ -473,6 +473,19 @@ class TestThreshold:
         assert expected.sum() > fewer.sum()  # the wide windows do add flags
         np.testing.assert_array_equal(expected, out)
 
+    @pytest.mark.parametrize("n_windows", [6, 8])
+    def test_sum_wide_windows_golden(self, n_windows, golden, context, command_queue):
+        """6 and 8 windows against flags produced by the imported reference itself
+        (tests/golden/make_golden.py, threshold_wide_case): these settings are no longer
+        pinned by the oracle alone."""
+        from katsdpsigproc_amd.rfi import device
+
+        dev, noise = inputs.threshold_wide_case()
+        template = device.ThresholdSumDeviceTemplate(context, n_windows=n_windows)
+        out = self._run(template, command_queue, dev, noise, n_sigma=6.0)
+        expected = unpack(golden[f"threshold_sum_f32_w{n_windows}"], dev.shape)
+        np.testing.assert_array_equal(expected, out)
+
     @pytest.mark.parametrize("vt", [8, 16, 32])
     @pytest.mark.parametrize("channels", [1500, 4096, 9001])
     def test_sum_every_vt(self, vt, channels, context, command_queue, oracle):

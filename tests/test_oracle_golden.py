@@ -126,6 +126,21 @@ def test_threshold_sum_params_golden(golden):
     )
 
 
+@pytest.mark.parametrize("n_windows", [6, 8])
+@pytest.mark.parametrize("kind", ["f32", "f64"])
+def test_threshold_sum_wide_windows_golden(golden, n_windows, kind):
+    """6 and 8 windows (window sums of 32 and 128 terms) against the imported reference:
+    the oracle adds left to right, numpy.convolve in an order of its own -- on these inputs
+    every flag agrees."""
+    dev, noise = inputs.threshold_wide_case()
+    if kind == "f64":
+        dev, noise = dev.astype(np.float64) * 1.0000001, noise.astype(np.float64) * 1.0000003
+    fl = oracle.ThresholdSumHost(6.0, n_windows=n_windows)(dev, noise)
+    expected = unpack(golden[f"threshold_sum_{kind}_w{n_windows}"], dev.shape)
+    assert 0.02 < expected.mean() < 0.6  # interference found, not everything flagged
+    np.testing.assert_array_equal(fl, expected)
+
+
 @pytest.mark.parametrize("name", ["simple", "sum"])
 @pytest.mark.parametrize("mode", ["none", "channel", "full"])
 def test_flagger_golden(golden, name, mode):

@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/r3d
-KSP_RING_TRACE=/tmp/ring.trace PAD=16 N=3 W=60 timeout -k 10 120 python tools/time_fused.py build/variants/lib_trace.so NONE 2>&1 | grep kernel
-python tools/trace_ring.py /tmp/ring.trace > gpurun_out/r3d/trace_cur.txt 2>&1; grep -v "^wg" gpurun_out/r3d/trace_cur.txt
+mkdir -p gpurun_out/r3f
+for v in h1 h1r; do
+PAD=16 timeout -k 10 120 python tools/time_fused.py build/variants/lib_$v.so NONE 2>&1 | grep kernel | tee -a gpurun_out/r3f/t2.txt
+PAD=16 timeout -k 10 120 python tools/time_fused.py build/variants/lib_$v.so NONE rfi 2>&1 | grep kernel | tee -a gpurun_out/r3f/t2.txt
+done

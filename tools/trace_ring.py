@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 STRIPS = 24
-t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(256, 8, STRIPS, 8).astype(np.int64)
+t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(256, 8, STRIPS, 16).astype(np.int64)
 valid = t[..., 7] > 0
 print("strips per workgroup: min %d max %d" % (valid[:, 0].sum(1).min(), valid[:, 0].sum(1).max()))
 s0, s1, s2, s3 = t[..., 0], t[..., 1], t[..., 2], t[..., 3]
@@ -19,6 +19,16 @@ for name, d in (("stream (ring, |z|, median)", s1 - s0), ("MAD", s2 - s1), ("thr
 for name, d in (("  of it: waiting for DMA", t[..., 5]), ("  of it: waiting at barriers", t[..., 6])):
     v = d[valid]
     print("%-28s mean %8.0f  median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (name, v.mean(), np.median(v), np.percentile(v, 10), np.percentile(v, 90)))
+# inside the MAD (fused_common.h, mad_noise stamps 8 .. 14)
+names = ["keys", "bit planes (transpose)", "key search", "candidate list", "exact recomputation", "ranking", "rest"]
+prev = s1
+for i, name in enumerate(names):
+    cur = t[..., 8 + i]
+    ok = valid & (cur > 0) & (prev > 0)
+    if ok.any():
+        v = (cur - prev)[ok]
+        print("    MAD: %-24s mean %7.0f  median %7.0f cycles" % (name, v.mean(), np.median(v)))
+    prev = np.where(cur > 0, cur, prev)
 # gap between strips of a wavefront (barriers, ticket)
 gap = s0[:, :, 1:] - s3[:, :, :-1]
 v = gap[valid[:, :, 1:]]
