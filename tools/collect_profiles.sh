@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/ktd -o bench --output-format csv -- pyt
 cp $(find /tmp/ktd -name "*kernel_stats.csv" | head -1) $OUT/bench_default_kernel_stats.csv
 for MODE in NONE CHANNEL; do
   i=0
-  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
+  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
     i=$((i+1))
     rm -rf /tmp/pm_$i
     FLAGS=$MODE N=3 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm_$i -o p --output-format csv -- python3 $R/tools/run_fused.py > /tmp/pm_$i.log 2>&1
@@ -40,10 +40,13 @@ for mode in ("NONE", "CHANNEL"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(out + f"/pmc_{mode}_pass*.csv")):
         for r in csv.DictReader(open(f)):
-            k = "fused" if "flagger_fused" in r["Kernel_Name"] else ("fill" if "fillBuffer" in r["Kernel_Name"] else None)
+            name = r["Kernel_Name"]
+            k = "fused" if ("flagger_ring" in name or "flagger_fused" in name) else ("fill" if "fillBuffer" in name else None)
             if k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    summary[mode] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+                acc[k].setdefault("__kernel__", []).append(name.split("(")[0])
+    summary[mode] = {k: {c: (sum(v) / len(v) if c != "__kernel__" else sorted(set(v))[0]) for c, v in d.items()}
+                     for k, d in acc.items()}
 json.dump(summary, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True))
 PY

@@ -28,10 +28,12 @@ for mode in ("NONE", "CHANNEL"):
     write = f["WRITE_SIZE"] * 1024
     entries.append({
         "channels": 4096, "baselines": 32768, "use_flags": mode,
-        "kernel": "flagger_fused_kernel<64,13>",
+        "kernel": f.get("__kernel__", "flagger kernel"),
         "hbm_bytes_per_launch": round(fetch + write),
         "fetch_bytes": round(fetch), "write_bytes": round(write),
-        "fill_kernel_write_bytes": round(s[mode]["fill"]["WRITE_SIZE"] * 1024),
+        # (without input flags the persistent kernel zero-fills the flags itself: its own
+        # WRITE_SIZE then holds the 128 MiB and there is no fill kernel)
+        "fill_kernel_write_bytes": round(s[mode]["fill"]["WRITE_SIZE"] * 1024) if "fill" in s[mode] else 0,
         "source": f"profiles/{rnd}_pmc_summary_{ver}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                   "passes; FETCH_SIZE doubled per the guide's gfx950 correction; cross-check "
                   f"TCC_EA0_RDREQ_sum x 128 B = {round(f['TCC_EA0_RDREQ_sum'] * 128)})",
