@@ -106,6 +106,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     };
     float dev[R];
     float dmax;
+    int tiny = 0;  // deviations of +-2^-150 (SortedWindow::tiny)
     bool merged = false;
     if constexpr (R == 64 && WIDTH <= 13) {
         // clean strip over the whole band: the merging median (median_merge.h; its
@@ -113,10 +114,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         if (!any_masked && C == 64 * R && FUSED_DIAG_STOP(p) != 21) {
             MergeMedian<R, WIDTH> mm;
             mm.template run_lane<LY::RUN - R>(myrow + lane * LY::RUN, lane, dev, dmax);
+            tiny = mm.tiny;
             merged = true;
         }
     }
-    if (!merged) median_phase<R, WIDTH>(myrow, lane, dev, dmax);
+    if (!merged) median_phase<R, WIDTH>(myrow, lane, dev, dmax, &tiny);
     stamp(3);
     const FusedParams &pa = p;
     if (FUSED_DIAG_STOP(pa) == 2) {
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
         return;
     }
 
-    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, FUSED_DIAG_STOP(pa), trace);
+    const double noise64 = mad_noise<R, WIDTH, LY::LIST_DOUBLES>(dev, lane, list, fetch, FUSED_DIAG_STOP(pa), trace, 0,
+                                                                        nullptr, tiny);
     if (lane == 0 && pa.noise != nullptr && bl < pa.baselines) pa.noise[bl] = (float)noise64;
     stamp(4);
     if (FUSED_DIAG_STOP(pa) == 3 || FUSED_DIAG_STOP(pa) > 30) return;

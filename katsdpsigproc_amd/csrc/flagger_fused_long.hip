@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64 * S, 1) void flagger_long_kernel(const FusedPara
     };
     float dev[NR][64];
     float dmax = -__builtin_inff();
+    int tiny = 0;  // deviations of +-2^-150 (SortedWindow::tiny)
     const bool merged = !any_masked && (C & 63) == 0 && WIDTH <= 13;
 #pragma unroll
     for (int g = 0; g < NR; g++) {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(64 * S, 1) void flagger_long_kernel(const FusedPara
                                [&](int i) { return run[i - (LONG_RUN - 64)]; },
                                [&](int i) { return run[i + (LONG_RUN - 64)]; }, grun == 0,
                                grun == runs - 1, dev[g], dm);
+                    tiny += mm.tiny;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 64; j++) dev[g][j] = 0.0f;
@@ -74,11 +76,11 @@ __global__ __launch_bounds__(64 * S, 1) void flagger_long_kernel(const FusedPara
                 const int c = c0 + i;
                 return (c >= 0 && c < 64 * runs) ? myrow[long_index(c)] : __builtin_nanf("");
             };
-            median_phase_src<64, WIDTH>(amp_rel, dev[g], dm);
+            median_phase_src<64, WIDTH>(amp_rel, dev[g], dm, &tiny);
         }
         dmax = fmaxf(dmax, dm);
     }
-    const double noise64 = mad_noise_long<NR, WIDTH, 256>(dev, lane, list, fetch);
+    const double noise64 = mad_noise_long<NR, WIDTH, 256>(dev, lane, list, fetch, tiny);
     if (lane == 0 && p.noise != nullptr) p.noise[bl] = (float)noise64;
     if (p.deviations != nullptr) {
 #pragma unroll

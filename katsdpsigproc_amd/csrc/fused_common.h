@@ -306,7 +306,8 @@ __device__ __forceinline__ bool load_strip_fast(const FusedParams &p, float *lds
 // General form: the samples are supplied by `amp_rel(i)`, -H <= i < R + H (NaN = takes
 // no part, including everything beyond the band).
 template <int R, int WIDTH, class Src>
-__device__ __forceinline__ void median_phase_src(Src &&amp_rel, float (&dev)[R], float &dmax)
+__device__ __forceinline__ void median_phase_src(Src &&amp_rel, float (&dev)[R], float &dmax,
+                                                 int *tiny = nullptr)
 {
     constexpr int H = WIDTH / 2;
     dmax = -__builtin_inff();
@@ -337,11 +338,12 @@ __device__ __forceinline__ void median_phase_src(Src &&amp_rel, float (&dev)[R],
             dev[j] = d;
         }
     }
+    if (tiny != nullptr) *tiny += win.tiny;
 }
 
 template <int R, int WIDTH>
 __device__ __forceinline__ void median_phase(const float *myrow, int lane, float (&dev)[R],
-                                             float &dmax)
+                                             float &dmax, int *tiny = nullptr)
 {
     using LY = FusedLayout<R>;
     constexpr int H = WIDTH / 2;
@@ -360,7 +362,7 @@ __device__ __forceinline__ void median_phase(const float *myrow, int lane, float
             return (c >= 0 && c < 64 * R) ? myrow[LY::index(c)] : nan;
         }
     };
-    median_phase_src<R, WIDTH>(amp_rel, dev, dmax);
+    median_phase_src<R, WIDTH>(amp_rel, dev, dmax, tiny);
 }
 
 // Exact float64 deviation of channel c, recomputed from the amplitudes of its window
@@ -644,12 +646,16 @@ __device__ __forceinline__ void rank_list_u32(const unsigned *vals, unsigned x, 
 // with two wave reductions instead of eight, whether the median lies under the same top
 // bits (neighbouring baselines mostly have noise of the same binade), and only otherwise
 // starts from the top.
+// `tiny`: how many of the lane's deviations are +-2^-150 exactly -- not zero, but zero as
+// float32 (SortedWindow::tiny). They have key 0 like the zeros and are told apart by count:
+// the host ranks them as the smallest non-zero values.
 // Returns the float64 noise estimate (NaN when every deviation is zero).
 template <int R, int WIDTH, int LIST_CAP, bool HAVE_EXACT = false, class Fetch>
 __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, double *list,
                                             Fetch &&fetch, int debug_stop = 0,
                                             unsigned long long *trace = nullptr,
-                                            unsigned long long exact = 0, int *top_hint = nullptr)
+                                            unsigned long long exact = 0, int *top_hint = nullptr,
+                                            int tiny = 0)
 {
     static_assert(!HAVE_EXACT || R == 64, "exactness masks are 64 bits, one per sample of a lane");
     constexpr int NP = R / 2;
@@ -689,6 +695,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     unsigned K = 0;
     int below_bin = 0, in_bin;
     int rank2 = 0, rank = 0;  // zeros sort first (reference rank.mako:261-266): rank2 = total + zeros
+    int zeros_keys = 0;       // samples with key 0: the zeros and the +-2^-150
     unsigned eq0 = 0, eq1 = 0;  // R == 64: which even / odd samples of the lane have key K
     if constexpr (R == 64) {
         // Bit-sliced search. The lane's 64 keys are transposed into 15 bit planes of
@@ -710,9 +717,13 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             }
             zeros = ksp_wave_sum_dpp(__popc(z0) + __popc(z1));
         }
+        zeros_keys = zeros;
+        if (ksp_any(tiny != 0)) zeros -= ksp_wave_sum_dpp(tiny);
         if (zeros == total) return __builtin_nan("");  // numpy: median of nothing
         rank2 = total + zeros;
         rank = rank2 / 2;
+        // (the median among the +-2^-150: both middle values of an even count are, too)
+        if (rank < zeros_keys) return 0x1p-150 * FUSED_MAD_NORMAL;
         eq0 = eq1 = 0xffffffffu;
         // two bits per step: the keys still matching the prefix split four ways by
         // (bit1, bit0); three counts decide both bits after ONE round of reductions
@@ -790,9 +801,12 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
 #endif
         in_bin = ksp_wave_sum_dpp(__popc(eq0) + __popc(eq1));
     } else {
+        zeros_keys = zeros;
+        if (ksp_any(tiny != 0)) zeros -= ksp_wave_sum(tiny);
         if (zeros == total) return __builtin_nan("");
         rank2 = total + zeros;
         rank = rank2 / 2;
+        if (rank < zeros_keys) return 0x1p-150 * FUSED_MAD_NORMAL;
         for (int bit = 14; bit >= 0; bit--) {
             const unsigned test = K | (1u << bit);
             const int c = count_less16<NP>(kp, test);
@@ -1052,7 +1066,10 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
             k2 = (kj < (int)K) ? max(k2, kj) : k2;
         }
         k2 = wave_max_int(k2);
-        unsigned long long bm = bin_mask((unsigned)k2);
+        // (nothing with a non-zero key below the bin: the value below it is a +-2^-150 --
+        // were there none, an even count could not have its lower median down here)
+        const bool below_is_tiny = k2 <= 0;
+        unsigned long long bm = bin_mask((unsigned)(below_is_tiny ? 0 : k2));
         // within that bin the largest float32 values are enough
         float b32 = 0.0f;
 #pragma unroll
@@ -1064,9 +1081,13 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
         for (int j = 0; j < R; j++)
             if (((bm >> j) & 1) && fabsf(dv(j)) == b32) top |= 1ull << j;
         bool recompute = true;
+        if (below_is_tiny) {
+            prev = 0x1p-150;
+            recompute = false;
+        }
         if constexpr (HAVE_EXACT) {
             // every sample at that value exact as it stands: the value itself
-            if (!ksp_any((top & ~exact) != 0)) {
+            if (recompute && !ksp_any((top & ~exact) != 0)) {
                 prev = (double)b32;
                 recompute = false;
             }
@@ -1124,7 +1145,7 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 const double d = (double)dev[j];
-                const double slack = fabs(d) * 0x1p-23;
+                const double slack = fabs(d) * 0x1p-23 + 0x1p-149;  // (subnormals round by up to 2^-150)
                 if (d - slack > thr)
                     fl |= 1ull << j;
                 else if (d + slack > thr)
@@ -1259,7 +1280,7 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
                 }
             }
             const bool valid = (c0 + j + w <= C);
-            const double slack = mag * 0x1p-23;
+            const double slack = mag * 0x1p-23 + w * 0x1p-149;  // (subnormals round by up to 2^-150 each)
             if (valid) {
                 if (s - slack > limit)
                     hits |= 1ull << j;

@@ -166,7 +166,7 @@ __device__ __forceinline__ bool load_strip_long_pairs(const FusedParams &p, floa
 // summed over the groups; sample (g, j) of a lane is channel ((g * 64 + lane) << 6) + j.
 template <int NR, int WIDTH, int LIST_CAP, class Fetch>
 __device__ __forceinline__ double mad_noise_long(const float (&dev)[NR][64], int lane,
-                                                 double *list, Fetch &&fetch)
+                                                 double *list, Fetch &&fetch, int tiny = 0)
 {
     auto chan0 = [&](int g) { return ((g * 64 + lane) << 6); };
     auto dv = [&](int g, int j) -> float {
@@ -206,9 +206,14 @@ __device__ __forceinline__ double mad_noise_long(const float (&dev)[NR][64], int
         }
         zeros = ksp_wave_sum_dpp(z);
     }
+    // (`tiny` deviations of +-2^-150, float32 zeros that the host counts as non-zero: see
+    // mad_noise in fused_common.h)
+    const int zeros_keys = zeros;
+    if (ksp_any(tiny != 0)) zeros -= ksp_wave_sum_dpp(tiny);
     if (zeros == total) return __builtin_nan("");  // numpy: median of nothing
     const int rank2 = total + zeros;  // zeros sort first (reference rank.mako:261-266)
     const int rank = rank2 / 2;
+    if (rank < zeros_keys) return 0x1p-150 * FUSED_MAD_NORMAL;
     unsigned K = 0;
     int below_bin = 0;
     unsigned eq0[NR], eq1[NR];
@@ -403,7 +408,8 @@ __device__ __forceinline__ double mad_noise_long(const float (&dev)[NR][64], int
                 k2 = (kj < (int)K) ? max(k2, kj) : k2;
             }
         k2 = wave_max_int(k2);
-        prev = largest_below(0xffffffffu, k2);
+        // (no non-zero key below the bin: the value below it is one of the +-2^-150)
+        prev = k2 <= 0 ? 0x1p-150 : largest_below(0xffffffffu, k2);
     }
     if (even) xk = (xk + prev) / 2.0;  // float64 mean, as numpy.median
     return xk * FUSED_MAD_NORMAL;

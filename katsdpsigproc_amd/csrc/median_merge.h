@@ -54,6 +54,7 @@ struct MergeMedian {
     static constexpr int S_SIZE = W * (W + 1) / 2;
 
     float pinf, ninf;  // opaque +-inf (med3 with them is min / max in one instruction)
+    int tiny = 0;      // non-zero deviations that round to a float32 zero (see SortedWindow::tiny)
 
     __device__ __forceinline__ float vmin(float a, float b) const
     {
@@ -162,8 +163,11 @@ struct MergeMedian {
                     constexpr bool right_odd = j + H >= R && ((j + H - R + 1) & 1);
                     if constexpr (left_odd || right_odd) {
                         const float lo = rank<W - t, t, H - 1>(&S[off(t)], P);
-                        if (left_odd ? first : last)
-                            d = (float)((double)xc - ((double)lo + (double)med) * 0.5);
+                        if (left_odd ? first : last) {
+                            const double dd = (double)xc - ((double)lo + (double)med) * 0.5;
+                            d = (float)dd;
+                            tiny += (d == 0.0f && dd != 0.0);
+                        }
                     }
                     dmax = vmax(dmax, d);
                     dev[j] = d;

@@ -30,6 +30,10 @@ struct SortedWindow {
     static constexpr int H = WIDTH / 2;
     float s[WIDTH];  // sorted ascending
     bool odd;        // #(+inf paddings) == #(-inf paddings) + 1
+    // deviations computed so far that are not zero but round to a float32 zero (+-2^-150: the
+    // mean of two subnormal samples against a third); the host counts them among the non-zero
+    // deviations of the MAD (rfi/host.py:161), so mad_noise() is told how many there are
+    int tiny = 0;
     float pinf, ninf;  // +-infinity, opaque to the optimiser (see reset)
 
     __device__ __forceinline__ void reset()
@@ -88,7 +92,7 @@ struct SortedWindow {
     // larger operand by far less than half a float32 ulp), so one v_sub_f32 suffices;
     // the float64 mean is only needed by lanes with an even count, and the whole
     // wavefront skips it when no lane has one.
-    __device__ __forceinline__ float deviation(float x) const
+    __device__ __forceinline__ float deviation(float x)
     {
         float d = x - s[H];
         if (odd) {
@@ -97,7 +101,9 @@ struct SortedWindow {
             asm volatile("");
             // x - (lo + hi) / 2 with one rounding: the sum is exact in float64, halving it
             // is exact, so the fused form equals the host's two steps
-            d = (float)__fma_rn(-0.5, (double)s[H > 0 ? H - 1 : 0] + (double)s[H], (double)x);
+            const double dd = __fma_rn(-0.5, (double)s[H > 0 ? H - 1 : 0] + (double)s[H], (double)x);
+            d = (float)dd;
+            tiny += (d == 0.0f && dd != 0.0);
         }
         return d;
     }

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         // float32 with exponent e. One bit per output, shifted into two accumulators in the
         // order the outputs appear. (NaN compares false: not exact.)
         unsigned ex_a = 0, ex_b = 0;
+        int tiny = 0;  // deviations of +-2^-150 (SortedWindow::tiny)
         auto note_exact = [&](unsigned &acc, float x, float m, float d) {
             unsigned t;
             asm("v_min_u32 %1, %2, %3\n\tv_or_b32 %1, 0x7fffff, %1\n\t"
@@ -490,7 +491,11 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                         constexpr bool right_odd = j + H >= R && ((j + H - R + 1) & 1);
                         if constexpr (right_odd) {
                             const float lo = mm.template rank<W - t, t, H - 1>(&S[MM::off(t)], P);
-                            if (last) d = (float)((double)xc - ((double)lo + (double)med) * 0.5);
+                            if (last) {
+                                const double dd = (double)xc - ((double)lo + (double)med) * 0.5;
+                                d = (float)dd;
+                                tiny += (d == 0.0f && dd != 0.0);
+                            }
                         }
                         // (pinned: the optimiser otherwise sinks the whole median below the
                         // last chunk, next to the first use of the deviations)
@@ -553,7 +558,11 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                     float d = xc - med;
                     if constexpr ((H - j) & 1) {
                         const float lo = mm.template rank<H - j, j + H + 1, H - 1>(&SL[soff(j)], PL);
-                        if (first) d = (float)((double)xc - ((double)lo + (double)med) * 0.5);
+                        if (first) {
+                            const double dd = (double)xc - ((double)lo + (double)med) * 0.5;
+                            d = (float)dd;
+                            tiny += (d == 0.0f && dd != 0.0);
+                        }
                     }
                     note_exact(ex_b, xc, med, d);
                     dmax = mm.vmax(dmax, d);
@@ -598,7 +607,8 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
             asm volatile("" : "+v"(c_first));  // (opaque: nothing of this path is hoisted out of the loop)
 #pragma unroll
             for (int i = 0; i < R + 2 * H; i++) a2[i] = fetch(c_first + i);
-            median_phase_src<R, W>([&](int i) { return a2[i + H]; }, dev, dmax);
+            tiny = 0;
+            median_phase_src<R, W>([&](int i) { return a2[i + H]; }, dev, dmax, &tiny);
             exact = 0;
         }
         // next but one strip, if it comes from the counters: the ticket of the own list is in
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
 #else
                                                                       nullptr,
 #endif
-                                                                      exact, &mad_hint);
+                                                                      exact, &mad_hint, tiny);
         if (lane == 0 && p.noise != nullptr) p.noise[bl] = (float)noise64;
         RING_STAMP(2);
 #if RING_STOP == 3 || RING_STOP > 30

@@ -94,6 +94,18 @@ def main() -> None:
         out[f"threshold_sum_f32_w{n_windows}"] = np.packbits(th(wide32, wide_noise32).astype(np.bool_))
         out[f"threshold_sum_f64_w{n_windows}"] = np.packbits(th(wide64, wide_noise64).astype(np.bool_))
 
+    # subnormal amplitudes with deviations of exactly +-2^-150 (zero as float32, counted by
+    # host.py:161): noise estimates, as amplitudes and as complex visibilities
+    den = inputs.denormal_case()
+    bg_den = host.BackgroundMedianFilterHost(13, True)
+    dev_den = bg_den(den)
+    assert np.count_nonzero(np.abs(dev_den) == 2.0 ** -150) >= 8
+    out["denormal_noise"] = host.NoiseEstMADHost()(dev_den)
+    dev_cplx = host.BackgroundMedianFilterHost(13)(den.astype(np.complex64))
+    assert np.array_equal(dev_cplx, dev_den)
+    out["denormal_flags"] = np.packbits(
+        host.ThresholdSumHost(11.0)(dev_den, out["denormal_noise"]).astype(np.bool_))
+
     # (ii-d) flagger 117x131 with injected RFI, three flag modes, Simple and Sum
     vis_f, _sp, in_flags = inputs.flagger_case()
     for name, th in (

@@ -147,3 +147,25 @@ def threshold_wide_case(seed=11):
         dev[rs.randint(0, channels, 2), b] += 40.0
     noise = (0.9 + 0.2 * rs.random_sample(baselines)).astype(np.float32)
     return dev, noise
+
+
+def denormal_case(channels=4096):
+    """Amplitudes that are small multiples of 2^-149 (float32 subnormals), 8 baselines: a
+    constant level of 20 units with two isolated spikes, and at one band edge a pattern under
+    which an even-count window yields a deviation of exactly +-2^-150 -- not zero, but zero
+    once rounded to float32 -- whose being counted among the non-zero deviations changes the
+    MAD (1 or 2 units of noise with it, 2 or 3 without: patterns found by search). Baselines
+    0-3 carry the pattern at the lower edge, 4-7 mirrored at the upper one.
+    Returns float32 [channels][8]."""
+    patterns = [[21, 18, 19, 19, 19, 18, 20, 22, 21, 21], [22, 22, 21, 22, 22, 22, 18, 22, 21, 20],
+                [20, 20, 21, 20, 21, 22, 22, 20, 19, 20], [19, 19, 18, 18, 20, 22, 21, 21, 20, 19]]
+    units = np.full((channels, 8), 20.0)
+    for b in range(8):
+        edge = np.array(patterns[b % 4], dtype=np.float64)
+        if b < 4:
+            units[:10, b] = edge
+            units[100, b], units[200, b] = 29, 23
+        else:
+            units[-10:, b] = edge[::-1]
+            units[channels - 101, b], units[channels - 201, b] = 29, 23
+    return (units * 2.0 ** -149).astype(np.float32)

@@ -545,6 +545,38 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @pytest.mark.parametrize("kind", ["amplitude", "complex", "long", "short"])
+    def test_deviations_of_2_to_minus_150(self, kind, golden, context, command_queue, oracle):
+        """Deviations of exactly +-2^-150 (an even-count window over subnormal amplitudes):
+        zero as float32, yet counted among the non-zero deviations by rfi/host.py:161. The
+        noise estimates are those of the imported reference (golden); they differ from what
+        taking such deviations for zeros would give. Amplitude input takes the 4-baseline
+        kernel, complex input the ring kernel as well, 8192 channels the long-band kernel,
+        256 channels the short-run variant."""
+        from katsdpsigproc_amd.rfi import device
+
+        channels = {"long": 8192, "short": 256}.get(kind, 4096)
+        amp = inputs.denormal_case(channels)
+        is_amp = kind != "complex"
+        vis = amp if is_amp else amp.astype(np.complex64)
+        ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, amplitudes=is_amp, want_deviations=True)
+        assert (np.abs(ref_dev) == 2.0 ** -150).any(axis=0).all()
+        if channels == 4096:
+            np.testing.assert_array_equal(ref_noise, golden["denormal_noise"])
+        naive = np.array([np.median(d[(d > 0) & (d != 2.0 ** -150)]) * 1.4826 for d in np.abs(ref_dev).T])
+        assert np.all(naive.astype(np.float32) != ref_noise.astype(np.float32))  # teeth
+        if is_amp:
+            bg = device.BackgroundMedianFilterDeviceTemplate(context, 13, is_amplitude=True)
+            template = device.FlaggerDeviceTemplate(
+                bg, device.NoiseEstMADTDeviceTemplate(context, 10240),
+                device.ThresholdSumDeviceTemplate(context), keep_deviations=True)
+        else:
+            template = make_template(context)
+        out = run_fused(template, command_queue, vis, n_sigma=11.0)
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), out["deviations"])
+        np.testing.assert_array_equal(ref_flags, out["flags"])
+
     @pytest.mark.parametrize("seed", [1, 2, 3])
     def test_full_band_interference_kinds(self, seed, context, command_queue, oracle):
         """4096 channels with narrow-band, broad-band (runs of 2-12 channels: windows 2, 4

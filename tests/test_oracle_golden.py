@@ -126,6 +126,22 @@ def test_threshold_sum_params_golden(golden):
     )
 
 
+def test_denormal_deviations_golden(golden):
+    """Deviations of exactly +-2^-150 (float32 zeros) count as non-zero in the MAD, as in the
+    imported reference; the case is built so that this changes the noise estimates."""
+    amp = inputs.denormal_case()
+    flags, noise, dev = oracle.flagger_full(amp, amplitudes=True, want_deviations=True)
+    tiny = np.abs(dev) == 2.0 ** -150
+    assert tiny.any(axis=0).all()
+    np.testing.assert_array_equal(noise, golden["denormal_noise"])
+    np.testing.assert_array_equal(flags, unpack(golden["denormal_flags"], amp.shape))
+    # teeth: with those deviations taken for zeros the float32 noise estimates differ
+    naive = np.array([np.median(d[(d > 0) & (d != 2.0 ** -150)]) * 1.4826 for d in np.abs(dev).T])
+    assert np.all(naive.astype(np.float32) != noise.astype(np.float32))
+    flags_c, noise_c = oracle.flagger_full(amp.astype(np.complex64))
+    np.testing.assert_array_equal(noise_c, noise)
+
+
 @pytest.mark.parametrize("n_windows", [6, 8])
 @pytest.mark.parametrize("kind", ["f32", "f64"])
 def test_threshold_sum_wide_windows_golden(golden, n_windows, kind):
