@@ -49,8 +49,6 @@ struct FusedParams {
     int n_static, n_dyn, dyn_blocks;
     unsigned *work;  // [0] next dynamic strip, [1] dynamic workgroups finished; zero between launches
     int first_round;  // workgroups resident at once (2 per CU): the first dispatch round
-    // ring kernel only: bytes of `flags` it zero-fills itself (0: the launcher's memset did)
-    unsigned long long zero_bytes;
 #ifdef KSP_DIAG
     int debug_stop;  // diagnostic builds only (env KSP_FUSED_DEBUG_STOP): 0 = run everything
     unsigned long long *trace;  // diagnostic builds only (env KSP_FUSED_DEBUG_TRACE): phase time stamps

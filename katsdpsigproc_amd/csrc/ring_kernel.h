@@ -69,7 +69,6 @@ __device__ unsigned long long ring_trace_buf[256 * 8 * RING_TRACE_STRIPS * RING_
 // workspace words used by this kernel (the 4-baseline kernels use [0], [1])
 #define RING_WORK_LIST 2   // [2 .. 9]: next ticket of XCD list x
 #define RING_WORK_DONE 10  // workgroups finished
-#define RING_WORK_ZERO 11  // workgroups whose share of the flags is zero-filled
 
 // ticket t of list x -> strip (runs of RING_XCD_GROUP strips per XCD); monotone in t
 __device__ __forceinline__ int ring_strip_of(int x, int t)
@@ -189,54 +188,10 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
     auto finish = [&]() {
         if (tid == 0 && atomicAdd(&p.work[RING_WORK_DONE], 1u) == gridDim.x - 1u) {
 #pragma unroll
-            for (int k = RING_WORK_LIST; k <= RING_WORK_ZERO; k++) p.work[k] = 0;
+            for (int k = RING_WORK_LIST; k <= RING_WORK_DONE; k++) p.work[k] = 0;
         }
-    };
-    // ---- zero-fill of `flags` (p.zero_bytes != 0): workgroup b clears 16-byte units
-    // [b * per_wg, (b + 1) * per_wg) of the array, thread i the units i, i + 512, ... of them,
-    // a few per chunk of the first half of its first strip, so that the stores trickle out
-    // beside the loads. They are write-through stores (sc0 sc1): once a wavefront's counter
-    // says they are done they are in memory, no cache write-back is needed, and the workgroup
-    // says so on a counter. No wavefront anywhere writes a flag byte before the counter has
-    // reached the number of workgroups. Every workgroup of the launch signals before it
-    // waits, so the wait always ends.
-    const unsigned long long zero_units = p.zero_bytes / 16;
-    const unsigned long long per_wg = (zero_units + gridDim.x - 1) / gridDim.x;
-    unsigned long long zero_at = (unsigned long long)blockIdx.x * per_wg + (unsigned)tid;  // next unit of this thread
-    unsigned long long zero_end = ((unsigned long long)blockIdx.x + 1) * per_wg;
-    if (zero_end > zero_units) zero_end = zero_units;
-    const int zero_rounds = (int)((per_wg + RING_THREADS - 1) / RING_THREADS);  // units per thread
-    const int zero_per_chunk = (zero_rounds + NCHUNK / 2 - 1) / (NCHUNK / 2);
-    auto zero_some = [&](int n) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = 0; i < n; i++) {
-            if (zero_at < zero_end)
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1"
-                             :: "v"(p.flags + zero_at * 16), "v"(z) : "memory");
-            zero_at += RING_THREADS;
-        }
-    };
-    bool zero_signalled = p.zero_bytes == 0, zero_seen = p.zero_bytes == 0;
-    // (every wavefront of the workgroup calls this together; `drain`: nothing is known about
-    // what was issued after the zero stores, wait for everything)
-    auto zero_signal = [&](bool drain) {
-        zero_some(zero_rounds);  // whatever is left (nothing after a whole first strip)
-        if (blockIdx.x == gridDim.x - 1 && tid < (int)(p.zero_bytes & 15))
-            p.flags[zero_units * 16 + tid] = 0;  // the bytes behind the last whole unit
-        // the zero stores of a whole first strip are older than the 16 requests of its second
-        // half that may still be in flight
-        if (drain)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_fetch_add(&p.work[RING_WORK_ZERO], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        zero_signalled = true;
     };
     if (cur < 0) {
-        if (!zero_signalled) zero_signal(true);
         finish();
         return;
     }
@@ -356,9 +311,6 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
                     issue(j % NSLOT);
                 }
             });
-            if constexpr (c < NCHUNK / 2) {
-                if (!zero_signalled) zero_some(zero_per_chunk);
-            }
             // chunk c + 1 into the other register set (chunk 0 of the next strip at the end)
             if (c + 1 < NCHUNK || more) {
                 // (one address per chunk, opaque: or the compiler keeps 16 slot addresses in
@@ -572,7 +524,6 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         }
 #endif
         RING_STAMP(1);
-        if (!zero_signalled) zero_signal(!more || (p.zero_bytes & 15) != 0);  // (first strip only)
 #ifdef RING_TRACE
         if (lane_id == 0 && trace_it < RING_TRACE_STRIPS && blockIdx.x < 256) {
             ring_trace_buf[((blockIdx.x * 8 + wave) * RING_TRACE_STRIPS + trace_it) * RING_TRACE_SLOTS + 5] = wait_dma;
@@ -641,17 +592,6 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
         if (noise64 == 12345.678 && p.noise != nullptr) p.noise[bl] = dmax;
 #else
         const unsigned long long fl = threshold_flags<R, W>(p, dev, dmax, noise64, lane, C, fetch);
-        if (!zero_seen && ksp_any(fl != 0)) {
-            // the first flags of this wavefront: every share of the array is zero by now?
-            // (bounded: a launch that cannot finish its zero-fill must not hang the device)
-            for (unsigned spins = 0; spins < (1u << 22); spins++) {
-                const unsigned done = __hip_atomic_load(&p.work[RING_WORK_ZERO], __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)__builtin_amdgcn_readfirstlane((int)done) >= gridDim.x) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
-            zero_seen = true;
-        }
         write_flags(p, fl, lane * R, bl, C);
         RING_STAMP(3);
 #endif

@@ -1014,9 +1014,22 @@ class FusedFlaggerDevice(accel.Operation):
     **input_flags** : channels or channels x baselines, uint8 (only with ``use_flags``)
     **noise** : baselines, float32 (float64 estimate rounded once)
     **flags** : channels x baselines, uint8
-    **deviations** : channels x baselines, float32 -- only if the template was built
-        with ``keep_deviations=True``
+    .. rubric:: Optional slots (the reference's temporaries, rfi/device.py:1081-1150)
+
+    **deviations** : channels x baselines, float32
+    **deviations_t** : baselines x channels, float32
+    **flags_t** : baselines x channels, uint8
+
+    The fused kernel needs none of them, so :meth:`ensure_all_bound` leaves them alone
+    (``deviations`` excepted if the template was built with ``keep_deviations=True``). They
+    exist all the same: binding one, or asking for it with :meth:`buffer` (which allocates
+    it), makes every later call fill it -- ``deviations`` by the kernel itself (13 instead of
+    9 bytes per sample, and the 4-baseline kernel instead of the persistent one), the
+    transposed ones by a transpose behind it. A buffer materialised after a call holds
+    nothing until the next call.
     """
+
+    _OPTIONAL = ("deviations", "deviations_t", "flags_t")
 
     def __init__(self, template: FlaggerDeviceTemplate, command_queue: AbstractCommandQueue,
                  channels: int, baselines: int, threshold_args: Mapping[str, Any] = {},
@@ -1058,23 +1071,53 @@ class FusedFlaggerDevice(accel.Operation):
         elif bg.use_flags == BackgroundFlags.CHANNEL:
             self.slots["input_flags"] = accel.IOSlot((channels,), np.uint8)
         self.slots["noise"] = accel.IOSlot((baselines,), np.float32)
-        self.slots["flags"] = accel.IOSlot((channels, accel.Dimension(baselines)), np.uint8)
-        if template.keep_deviations:
-            self.slots["deviations"] = accel.IOSlot(
-                (channels, accel.Dimension(baselines)), np.float32
-            )
+        # flags and deviations are shared with the source slots of two transposes that only
+        # run when somebody has bound their destinations (the reference's flags_t / deviations_t)
+        context = command_queue.context
+        self._transpose_dev = transpose.TransposeTemplate(context, np.float32, "float").instantiate(
+            command_queue, (channels, baselines), allocator=allocator)
+        self._transpose_flags = transpose.TransposeTemplate(
+            context, np.uint8, "unsigned char").instantiate(
+            command_queue, (channels, baselines), allocator=allocator)
+        self.slots["flags"] = accel.CompoundIOSlot([
+            accel.IOSlot((channels, accel.Dimension(baselines)), np.uint8),
+            self._transpose_flags.slots["src"]])
+        self.slots["deviations"] = accel.CompoundIOSlot([
+            accel.IOSlot((channels, accel.Dimension(baselines)), np.float32),
+            self._transpose_dev.slots["src"]])
+        self.slots["deviations_t"] = self._transpose_dev.slots["dest"]
+        self.slots["flags_t"] = self._transpose_flags.slots["dest"]
+        self._mandatory = [name for name in self.slots
+                           if name not in self._OPTIONAL
+                           or (name == "deviations" and template.keep_deviations)]
         # scheduling counters of the kernel (64 bytes, zeroed once; not a slot: nothing a
         # caller could usefully bind)
         self._workspace = accel.DeviceArray(command_queue.context, (16,), np.uint32)
         self._workspace.zero(command_queue)
         self._armed = None
 
+    def ensure_all_bound(self) -> None:
+        for name in self._mandatory:
+            self.ensure_bound(name)
+
+    def buffer(self, name: str) -> accel.DeviceArray:
+        if name in self._OPTIONAL and not self.slots[name].is_bound():
+            self.ensure_bound(name)  # materialise: filled by every call from now on
+        return super().buffer(name)
+
+    def required_bytes(self) -> int:
+        return sum(slot.required_bytes() for name, slot in self.slots.items()
+                   if name in self._mandatory or slot.is_bound())
+
     def _run(self) -> None:
         bg = self.template.background
         vis = self.buffer("vis")
         flags = self.buffer("flags")
         in_flags = self.buffer("input_flags") if bg.use_flags else None
-        dev = self.buffer("deviations") if "deviations" in self.slots else None
+        want_dev_t = self.slots["deviations_t"].is_bound()
+        if want_dev_t:
+            self.ensure_bound("deviations")
+        dev = super().buffer("deviations") if self.slots["deviations"].is_bound() else None
         in_flags_stride = in_flags.padded_shape[1] if bg.use_flags == BackgroundFlags.FULL else 0
         self.command_queue.enqueue_kernel(
             self.kernel,
@@ -1102,6 +1145,10 @@ class FusedFlaggerDevice(accel.Operation):
             ],
         )
         self._armed = None  # (events of profile_next_run are recorded now: ours to drop)
+        if want_dev_t:
+            self._transpose_dev()
+        if self.slots["flags_t"].is_bound():
+            self._transpose_flags()
 
     def profile_next_run(self):
         """Arm two events around the flagger kernel of the next call (excluding the
@@ -1120,7 +1167,7 @@ class FusedFlaggerDevice(accel.Operation):
         return {
             "fused": True,
             "vis_pad": self.vis_pad,
-            "keep_deviations": "deviations" in self.slots,
+            "keep_deviations": self.slots["deviations"].is_bound(),
             "width": self.template.background.width,
             "n_sigma": self.n_sigma,
             "n_windows": self.n_windows,

@@ -134,19 +134,46 @@ def test_flagger_sequence_wiring(context, queue):
 
 
 def test_fused_selection_and_slots(context, queue):
-    # deviations is a temporary of the reference's flagger: absent unless asked for
+    # the reference's slot set (rfi/device.py:1081-1150) is there, but its temporaries are
+    # optional: not allocated by ensure_all_bound, not computed unless bound or asked for
+    temporaries = {"deviations", "deviations_t", "flags_t"}
     fn = templates(context).instantiate(queue, 4096, 64, threshold_args={"n_sigma": 11.0})
     assert isinstance(fn, device.FusedFlaggerDevice)
-    assert set(fn.slots) == {"vis", "noise", "flags"}
+    assert set(fn.slots) == {"vis", "noise", "flags"} | temporaries
     assert fn.parameters()["fused"] and not fn.parameters()["keep_deviations"]
+    fn.ensure_all_bound()
+    assert not any(fn.slots[name].is_bound() for name in temporaries)
+    lean_bytes = fn.required_bytes()
+    assert lean_bytes == sum(fn.slots[n].required_bytes() for n in ("vis", "noise", "flags"))
+    before = len(queue.launches)
     fn()
+    assert [n for n, _ in queue.launches[before:]] == ["ksp_flagger_fused"]
     name, args = queue.launches[-1]
     assert name == "ksp_flagger_fused" and args[3] is None
+    # asking for a temporary materialises it; later calls fill it
+    dev_t = fn.buffer("deviations_t")
+    assert dev_t.shape == (64, 4096) and fn.slots["deviations_t"].is_bound()
+    before = len(queue.launches)
+    fn()
+    assert [n for n, _ in queue.launches[before:]] == ["ksp_flagger_fused", "ksp_transpose"]
+    assert queue.launches[before][1][3] is not None  # the kernel now writes deviations
+    assert fn.slots["deviations"].is_bound() and fn.parameters()["keep_deviations"]
+    assert fn.required_bytes() > lean_bytes
+    fn.bind(flags_t=fn.slots["flags_t"].allocate(fn.allocator, bind=False))
+    before = len(queue.launches)
+    fn()
+    assert [n for n, _ in queue.launches[before:]] == ["ksp_flagger_fused", "ksp_transpose", "ksp_transpose"]
+    with pytest.raises(KeyError):
+        fn.buffer("no_such_slot")
+    fn = templates(context).instantiate(queue, 4096, 64, threshold_args={"n_sigma": 11.0})
+    fn()
+    name, args = queue.launches[-1]
     assert [int(a) for a in args[5:15]] == [4096, 64, 64, 0, 64, 0, 13, 0, 0, 1]
     fn = templates(context, keep_deviations=True).instantiate(
         queue, 4096, 64, threshold_args={"n_sigma": 11.0})
-    assert set(fn.slots) == {"vis", "noise", "flags", "deviations"}
-    assert fn.parameters()["keep_deviations"]
+    assert set(fn.slots) == {"vis", "noise", "flags"} | temporaries
+    fn.ensure_all_bound()
+    assert fn.slots["deviations"].is_bound() and fn.parameters()["keep_deviations"]
     fn()
     name, args = queue.launches[-1]
     assert name == "ksp_flagger_fused"
@@ -154,7 +181,7 @@ def test_fused_selection_and_slots(context, queue):
     assert args[15] == 11.0 and list(args[16]) == [1.2**-i for i in range(4)]
     lean = templates(context, device.BackgroundFlags.FULL, keep_deviations=False).instantiate(
         queue, 1024, 16, threshold_args={"n_sigma": 11.0, "threshold_falloff": 1.5})
-    assert set(lean.slots) == {"vis", "input_flags", "noise", "flags"}
+    assert set(lean.slots) == {"vis", "input_flags", "noise", "flags"} | temporaries
     assert list(lean.scales) == [1.5**-i for i in range(4)]
     # row padding of vis: from the template's tuning, into the slot's requirement and the stride
     padded = templates(context, tuning={"vis_pad": 32}).instantiate(

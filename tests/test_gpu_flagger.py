@@ -78,7 +78,7 @@ def run_fused(template, command_queue, vis, in_flags=None, **threshold_args):
     fn()
     out = {"flags": fn.buffer("flags").get(command_queue),
            "noise": fn.buffer("noise").get(command_queue)}  # fmt: skip
-    if "deviations" in fn.slots:
+    if template.keep_deviations:
         out["deviations"] = fn.buffer("deviations").get(command_queue)
     check_ring_path(template, command_queue, vis, in_flags, threshold_args, out)
     return out
@@ -356,6 +356,36 @@ class TestFused:
         out = run_fused(template, command_queue, vis, n_sigma=11.0)
         assert "deviations" not in out
         np.testing.assert_array_equal(oracle.flagger_full(vis)[0], out["flags"])
+
+    @pytest.mark.parametrize("channels, baselines", [(4096, 24), (600, 30)])
+    def test_optional_slots(self, channels, baselines, context, command_queue, oracle):
+        """The reference's temporaries on the default flagger (reference rfi/device.py:1081-1150):
+        left alone by ensure_all_bound, materialised by buffer() / bind(), filled by the calls
+        that follow -- deviations by the kernel, deviations_t and flags_t by a transpose."""
+        from katsdpsigproc_amd import _lib
+        from katsdpsigproc_amd.rfi import device
+
+        vis = inputs.add_rfi(inputs.generate_data(channels, baselines, seed=19), seed=20)
+        ref_flags, ref_noise, ref_dev = oracle.flagger_full(vis, want_deviations=True)
+        template = make_template(context, keep_deviations=False)
+        fn = template.instantiate(command_queue, channels, baselines, threshold_args={"n_sigma": 11.0})
+        assert isinstance(fn, device.FusedFlaggerDevice)
+        fn.ensure_all_bound()
+        assert not fn.slots["deviations"].is_bound()
+        fn.buffer("vis").set(command_queue, vis)
+        fn()
+        if channels == 4096:
+            assert _lib.call("ksp_flagger_fused_last_path") & 4  # nothing optional: the ring kernel
+        np.testing.assert_array_equal(ref_flags, fn.buffer("flags").get(command_queue))
+        flags_t = fn.buffer("flags_t")  # materialised now, filled by the next call
+        dev_t = fn.buffer("deviations_t")
+        assert flags_t.shape == (baselines, channels) and dev_t.shape == (baselines, channels)
+        fn()
+        np.testing.assert_array_equal(ref_flags, fn.buffer("flags").get(command_queue))
+        np.testing.assert_array_equal(ref_flags.T, flags_t.get(command_queue))
+        np.testing.assert_array_equal(ref_dev.astype(np.float32).T, dev_t.get(command_queue))
+        np.testing.assert_array_equal(ref_dev.astype(np.float32), fn.buffer("deviations").get(command_queue))
+        np.testing.assert_array_equal(ref_noise.astype(np.float32), fn.buffer("noise").get(command_queue))
 
     def test_amplitude_input_and_params(self, context, command_queue, oracle):
         from katsdpsigproc_amd.rfi import device

@@ -70,11 +70,11 @@ class TestTranspose:
         np.testing.assert_array_equal(ary.T, dest.get(command_queue))
 
     @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
-    def test_big_aligned(self, dtype, context, command_queue):
+    @pytest.mark.parametrize("R, C", [(4096, 2048), (4096, 4096)])  # (the second: BASELINE config 2)
+    def test_big_aligned(self, R, C, dtype, context, command_queue):
         """Config-2-sized transpose (vector path, 128-byte aligned rows)."""
         from katsdpsigproc_amd import transpose
 
-        R, C = 4096, 2048
         fn = transpose.TransposeTemplate(context, dtype, "x").instantiate(command_queue, (R, C))
         ary = np.random.RandomState(2).randint(0, 250, size=(R, C)).astype(dtype)
         fn.ensure_all_bound()
@@ -97,6 +97,7 @@ class TestPercentile5:
             (4094, 4030, False, (100, 4030)),
             (2343, 6031, False, (123, 4001)),
             (4092, 4032, True, None),
+            (4096, 4096, True, None),  # BASELINE config 2, exactly
             (7, 16384, True, None),
         ],
     )
@@ -298,7 +299,8 @@ class TestNoiseEst:
                                        (1025, 5), (2500, 7),
                                        # the reference script's presets (rfiflagtest.py:190-195)
                                        (8192, 21), (10240, 70), (8191, 3), (6000, 5),
-                                       (16384, 4)])  # fmt: skip
+                                       (16384, 4),
+                                       (4096, 8192)])  # BASELINE config 3, exactly  # fmt: skip
     def test_result(self, kind, shape, context, command_queue, oracle):
         # reference test/rfi/test_noise_est.py:54-79; exact instead of rtol 1e-7
         from katsdpsigproc_amd.rfi import device
