@@ -125,9 +125,13 @@ class StagedFlagger:
         self._submitted += 1
         return self._submitted - 1
 
-    def collect(self) -> Tuple[np.ndarray, np.ndarray]:
+    def collect(self, copy: bool = False) -> Tuple[np.ndarray, np.ndarray]:
         """(flags, noise) of the oldest block in flight, waiting for it if necessary.
-        The arrays are views of pinned buffers that are reused `depth` blocks later."""
+
+        Without `copy` the arrays are VIEWS of this block's pinned buffers, which the download
+        of the block submitted `depth` submissions later overwrites: they are valid until
+        that :meth:`submit` (in :meth:`run`: until the generator is advanced again). Pass
+        ``copy=True``, or copy what has to live longer."""
         if self._collected >= self._submitted:
             raise RuntimeError("no block is in flight")
         entry = self._sets[self._collected % self.depth]
@@ -135,21 +139,25 @@ class StagedFlagger:
         for queue in (self.upload, self.download):
             queue.release_host_references()
         self._collected += 1
+        if copy:
+            return entry["flags"].copy(), entry["noise"].copy()
         return entry["flags"], entry["noise"]
 
     # ------------------------------------------------------------------ a stream
-    def run(self, blocks: Iterable) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+    def run(self, blocks: Iterable, copy: bool = False) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
         """Flag every block of `blocks` (arrays, or ``(vis, input_flags)`` pairs), yielding
-        (flags, noise) in order while keeping up to `depth` blocks in flight."""
+        (flags, noise) in order while keeping up to `depth` blocks in flight. What is yielded
+        is only valid until the generator is advanced (see :meth:`collect`) unless `copy` is
+        set -- ``list(staged.run(blocks))`` needs ``copy=True``."""
         for block in blocks:
             if self._submitted - self._collected >= self.depth:
-                yield self.collect()
+                yield self.collect(copy)
             if isinstance(block, tuple):
                 self.submit(*block)
             else:
                 self.submit(block)
         while self._collected < self._submitted:
-            yield self.collect()
+            yield self.collect(copy)
 
     def finish(self) -> None:
         for queue in (self.upload, self.compute, self.download):
