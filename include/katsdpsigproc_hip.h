@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KSP_ABI_VERSION 3
+#define KSP_ABI_VERSION 4
 
 /* BackgroundFlags (reference: rfi/device.py:40-46) */
 #define KSP_FLAGS_NONE 0

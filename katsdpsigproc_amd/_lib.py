@@ -14,7 +14,7 @@ from ctypes import c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_native", "libkatsdpsigproc_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

@@ -238,11 +238,14 @@ extern "C" int ksp_background_median_filter(int device, void *stream, const void
         KSP_BG(17);
         KSP_BG(19);
         KSP_BG(21);
+        KSP_BG(23);
         KSP_BG(25);
+        KSP_BG(27);
+        KSP_BG(29);
         KSP_BG(31);
     default:
         ksp_set_error("ksp_background_median_filter: width %d has no compiled kernel "
-                      "(available: odd 3..21, 25, 31)", width);
+                      "(available: odd 3..31)", width);
         return (int)hipErrorInvalidValue;
     }
 #undef KSP_BG

@@ -42,6 +42,10 @@ int ksp_fused_launch_w15_17(int width, int device, hipStream_t s, const FusedPar
                             hipEvent_t ev0, hipEvent_t ev1);
 int ksp_fused_launch_w19_21(int width, int device, hipStream_t s, const FusedParams &p,
                             hipEvent_t ev0, hipEvent_t ev1);
+int ksp_fused_launch_w23_27(int width, int device, hipStream_t s, const FusedParams &p,
+                            hipEvent_t ev0, hipEvent_t ev1);
+int ksp_fused_launch_w29_31(int width, int device, hipStream_t s, const FusedParams &p,
+                            hipEvent_t ev0, hipEvent_t ev1);
 
 // more than 4096 channels (flagger_fused_long.hip)
 int ksp_fused_long_supported(int channels, int width);
@@ -59,7 +63,9 @@ static int ksp_fused_launch_other_width(int width, int device, hipStream_t s,
     if (width <= 7) return ksp_fused_launch_w3_7(width, device, s, p, ev0, ev1);
     if (width <= 11) return ksp_fused_launch_w9_11(width, device, s, p, ev0, ev1);
     if (width <= 17) return ksp_fused_launch_w15_17(width, device, s, p, ev0, ev1);
-    return ksp_fused_launch_w19_21(width, device, s, p, ev0, ev1);
+    if (width <= 21) return ksp_fused_launch_w19_21(width, device, s, p, ev0, ev1);
+    if (width <= 27) return ksp_fused_launch_w23_27(width, device, s, p, ev0, ev1);
+    return ksp_fused_launch_w29_31(width, device, s, p, ev0, ev1);
 }
 
 extern "C" int ksp_flagger_fused_profile(void *start_event, void *stop_event)
@@ -76,7 +82,7 @@ extern "C" int ksp_flagger_fused_supported(int channels, int width, int n_window
 {
     if (n_windows < 1 || n_windows > 4) return 0;
     if (channels > 4096) return ksp_fused_long_supported(channels, width);
-    return channels >= 1 && width >= 3 && width <= 21 && (width & 1);
+    return channels >= 1 && width >= 3 && width <= 31 && (width & 1);
 }
 
 extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,

@@ -1,7 +1,7 @@
 // The fused flagger kernel and its launcher as templates over (R = channels per lane,
 // WIDTH = median window): flagger_fused.hip instantiates width 13 (the reference
 // script's, scripts/rfiflagtest.py:71) for R = 4, 16, 64, the flagger_fused_w*.hip files
-// the other odd widths 3..21 for R = 64 -- one translation unit per few widths so that
+// the other odd widths 3..31 for R = 64 -- one translation unit per few widths so that
 // they compile in parallel.
 #pragma once
 #include <hip/hip_ext.h>

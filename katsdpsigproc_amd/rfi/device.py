@@ -127,7 +127,7 @@ class BackgroundMedianFilterDeviceTemplate(AbstractBackgroundDeviceTemplate):
     context
         Context whose device will run the kernel
     width
-        Window width in channels: odd, one of 3..21, 25, 31
+        Window width in channels: odd, 3 to 31
     is_amplitude
         Inputs are float32 amplitudes rather than complex64 visibilities
     use_flags
@@ -142,7 +142,7 @@ class BackgroundMedianFilterDeviceTemplate(AbstractBackgroundDeviceTemplate):
 
     host_class = host.BackgroundMedianFilterHost
     autotune_version = 5
-    SUPPORTED_WIDTHS = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 25, 31)
+    SUPPORTED_WIDTHS = tuple(range(3, 32, 2))
 
     def __init__(self, context: AbstractContext, width: int, is_amplitude: bool = False,
                  use_flags: Union[BackgroundFlags, bool] = BackgroundFlags.NONE,

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_abi_version_and_no_device_calls(lib):
     from katsdpsigproc_amd import _lib
 
-    assert lib.ksp_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.ksp_abi_version() == _lib.ABI_VERSION == 4
     count = ctypes.c_int(-1)
     assert lib.ksp_device_count(ctypes.byref(count)) == 0
     assert count.value >= 0  # 0 in the CPU container
@@ -49,7 +49,10 @@ def test_abi_version_and_no_device_calls(lib):
     assert lib.ksp_flagger_fused_supported(12289, 13, 4) == 0
     assert lib.ksp_flagger_fused_supported(8192, 5, 4) == 0
     assert lib.ksp_flagger_fused_supported(4096, 5, 4) == 1
-    assert lib.ksp_flagger_fused_supported(4096, 25, 4) == 0
+    assert lib.ksp_flagger_fused_supported(4096, 25, 4) == 1  # (round 3: widths up to 31)
+    assert lib.ksp_flagger_fused_supported(4096, 33, 4) == 0
+    assert lib.ksp_flagger_fused_supported(4096, 13, 5) == 0
+    assert lib.ksp_flagger_fused_last_path() == 0  # no launch yet on this thread
     assert lib.ksp_flagger_fused_supported(4096, 12, 4) == 0
     assert lib.ksp_flagger_fused_supported(4096, 13, 5) == 0
 

@@ -245,7 +245,7 @@ class TestFused:
         np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
-    @pytest.mark.parametrize("width", [3, 5, 7, 9, 11, 15, 17, 19, 21])
+    @pytest.mark.parametrize("width", [3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25, 27, 29, 31])
     @pytest.mark.parametrize("channels, baselines, mode",
                              [(4096, 12, "none"), (4096, 8, "channel"), (1000, 9, "full"),
                               (40, 5, "none")])  # fmt: skip
@@ -630,16 +630,24 @@ class TestFused:
     def test_unsupported_falls_back_to_sequence(self, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
+        def six_windows(**kw):
+            return device.FlaggerDeviceTemplate(
+                device.BackgroundMedianFilterDeviceTemplate(context, 13),
+                device.NoiseEstMADTDeviceTemplate(context, 10240),
+                device.ThresholdSumDeviceTemplate(context, n_windows=6), **kw)
+
+        fn = six_windows().instantiate(command_queue, 64, 8, threshold_args=dict(n_sigma=11.0))
+        assert isinstance(fn, device.FlaggerDevice)  # more than 4 windows: kernel per stage
         fn = make_template(context, width=25).instantiate(
             command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
         )
-        assert isinstance(fn, device.FlaggerDevice)
+        assert isinstance(fn, device.FusedFlaggerDevice)  # (round 3: widths up to 31 fuse)
         fn = make_template(context, noise="MAD").instantiate(
             command_queue, 12289, 8, threshold_args=dict(n_sigma=11.0)
         )
         assert isinstance(fn, device.FlaggerDevice)  # beyond the fused kernels' 12288 channels
         with pytest.raises(ValueError):
-            make_template(context, width=25, fused=True).instantiate(
+            six_windows(fused=True).instantiate(
                 command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
             )
 

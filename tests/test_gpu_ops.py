@@ -208,6 +208,21 @@ class TestBackground:
         out = bg_device(vis, flags) if flags is not None else bg_device(vis)
         np.testing.assert_array_equal(expected.astype(np.float32), out)
 
+    @pytest.mark.parametrize("width", list(range(3, 32, 2)))
+    def test_every_width(self, width, context, command_queue, oracle):
+        """Every compiled window width (odd, 3 to 31), per-sample flags."""
+        from katsdpsigproc_amd.rfi import device
+
+        vis_big, flags_big = inputs.background_case()
+        template = device.BackgroundMedianFilterDeviceTemplate(
+            context, width, False, device.BackgroundFlags.FULL
+        )
+        out = device.BackgroundHostFromDevice(template, command_queue)(vis_big, flags_big)
+        expected = oracle.BackgroundMedianFilterHost(width)(vis_big, flags_big)
+        np.testing.assert_array_equal(expected.astype(np.float32), out)
+        with pytest.raises(ValueError):
+            device.BackgroundMedianFilterDeviceTemplate(context, width + 1)
+
     @pytest.mark.parametrize("mode", ["NONE", "CHANNEL"])
     def test_config3_shape(self, mode, context, command_queue, oracle):
         """4096 channels x 8192 baselines (BASELINE.json config 3, the reference's own

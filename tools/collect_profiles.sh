@@ -11,6 +11,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export KATSDPSIGPROC_TUNE_DB=/tmp/ksp_tune_$TAG.db
 # (fill the tuning cache first: the profiled runs then launch nothing but what they measure)
 python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --preheat 0 > $OUT/bench_warm_cache.log 2>&1
 FLAGS=CHANNEL N=1 python3 $R/tools/run_fused.py >> $OUT/bench_warm_cache.log 2>&1
