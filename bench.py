@@ -352,6 +352,27 @@ def bringup_configs(context, queue, vis_host) -> dict:
             must(np.array_equal(fn.buffer("flags").get(queue)[:, :SL], ref_flags),
                  f"flags of the first {SL} baselines == oracle"))
     del fn
+    # configurations the fused kernels refused before round 3 (they took the five-kernel
+    # sequence): a median window of 25 channels; SumThreshold with 8 windows (up to 128 channels)
+    for key, width, n_windows in (("flagger_fused_width25_4096x8192", 25, 4),
+                                  ("flagger_fused_8_windows_4096x8192", WIDTH, 8)):  # fmt: skip
+        template = device.FlaggerDeviceTemplate(
+            device.BackgroundMedianFilterDeviceTemplate(context, width),
+            device.NoiseEstMADTDeviceTemplate(context, 10240),
+            device.ThresholdSumDeviceTemplate(context, n_windows=n_windows),
+            fused=True,
+        )
+        fn = template.instantiate(queue, C, B, threshold_args={"n_sigma": N_SIGMA})
+        fn.ensure_all_bound()
+        fn.buffer("vis").set(queue, block)
+        seconds = time_op(queue, fn)
+        ref_flags, _ = oracle.flagger_full(block[:, :SL], width=width, n_sigma=N_SIGMA,
+                                           n_windows=n_windows)  # fmt: skip
+        out[key] = entry(
+            seconds, 9 * C * B, "9 B/sample",
+            must(np.array_equal(fn.buffer("flags").get(queue)[:, :SL], ref_flags),
+                 f"flags of the first {SL} baselines == oracle"))
+    del fn
     # the reference script's wider presets (scripts/rfiflagtest.py:190-195): the same
     # number of samples laid out as 8192 and 10240 channels (fused long-band kernels)
     for channels in (8192, 10240):

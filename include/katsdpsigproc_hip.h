@@ -185,7 +185,9 @@ int ksp_flagger_fused(int device, void *stream, const void *vis, const uint8_t *
 int ksp_flagger_fused_profile(void *start_event, void *stop_event);
 
 /* Returns 1 if ksp_flagger_fused supports this configuration (else callers fall
- * back to the kernel-per-stage sequence). */
+ * back to the kernel-per-stage sequence): up to 4096 channels with any odd width 3 .. 31
+ * and 1 .. 8 SumThreshold windows (rfi/device.py:840-852 takes any n_windows); 4097 ..
+ * 12288 channels with width 13 and at most 4 windows. */
 int ksp_flagger_fused_supported(int channels, int width, int n_windows);
 
 /* Which kernels the calling thread's LAST ksp_flagger_fused call launched (no reference
@@ -193,8 +195,10 @@ int ksp_flagger_fused_supported(int channels, int width, int n_windows);
  * 1 = flagger_fused_kernel (strips of 4 baselines, up to 4096 channels),
  * 2 = flagger_long_kernel (4097-12288 channels),
  * 4 = flagger_ring_kernel (persistent, strips of 8 baselines, 4096 channels, complex input
- *     without input flags, no deviations output); 5 = ring kernel plus the 4-baseline kernel
- *     for a remainder of fewer than 8 baselines. */
+ *     without input flags, no deviations output, at most 4 windows; chosen from about 4
+ *     strips per compute unit on, or whenever possible / never with KSP_FUSED_RING=1 / 0 in
+ *     the environment); 5 = ring kernel plus the 4-baseline kernel for a remainder of fewer
+ *     than 8 baselines. */
 int ksp_flagger_fused_last_path(void);
 
 /* Self-tests of the arithmetic building blocks (no reference counterpart; they exist

@@ -80,8 +80,8 @@ extern "C" int ksp_flagger_fused_last_path(void) { return g_last_path; }
 
 extern "C" int ksp_flagger_fused_supported(int channels, int width, int n_windows)
 {
-    if (n_windows < 1 || n_windows > 4) return 0;
-    if (channels > 4096) return ksp_fused_long_supported(channels, width);
+    if (n_windows < 1 || n_windows > KSP_MAX_WINDOWS) return 0;
+    if (channels > 4096) return n_windows <= 4 && ksp_fused_long_supported(channels, width);
     return channels >= 1 && width >= 3 && width <= 31 && (width & 1);
 }
 
@@ -167,9 +167,14 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     hipStream_t s = (hipStream_t)stream;
     // The persistent ring kernel takes the whole strips of 8 baselines of a 4096-channel
     // launch without input flags; a ragged remainder (< 8 baselines) goes to the
-    // 4-baseline kernel. KSP_FUSED_NO_RING=1 (diagnostics) keeps everything on the latter.
+    // 4-baseline kernel.
+    // It pays from about 4 strips per workgroup on (measured, tools/time_ring_sizes.py: 0.089 ms
+    // against 0.065 at 4096 baselines, 0.133 = 0.132 at 8192, 0.218 against 0.236 at 16384,
+    // 0.384 against 0.431 at 32768); KSP_FUSED_RING=1 / 0 (tests, diagnostics) forces the choice.
     static const bool no_ring = getenv("KSP_FUSED_NO_RING") != nullptr;
-    if (!no_ring && width == 13 && ksp_ring_supported(p, width)) {
+    const char *force = getenv("KSP_FUSED_RING");
+    const bool want_ring = force != nullptr ? force[0] == '1' : (!no_ring && baselines / 8 >= 4 * n_cu);
+    if (want_ring && width == 13 && ksp_ring_supported(p, width)) {
         // (Letting the ring kernel zero-fill `flags` itself -- write-through stores beside the
         // first strip's loads, a completion counter before the first flag byte -- was built
         // and measured: step time unchanged, 0.376 against 0.377 ms clean and 0.518 against
@@ -196,7 +201,8 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     g_last_path = channels > 4096 ? 2 : 1;
     if (channels > 4096) return ksp_fused_launch_long(device, s, p, ev0, ev1);
     if (width != 13) return ksp_fused_launch_other_width(width, device, s, p, ev0, ev1);
-    if (channels <= 64 * 4) return launch_fused<4, 13>(device, s, p, ev0, ev1);
-    if (channels <= 64 * 16) return launch_fused<16, 13>(device, s, p, ev0, ev1);
+    const bool wide = threshold_kind == KSP_THRESHOLD_SUM && n_windows > 4;  // (lanes of 64 channels)
+    if (channels <= 64 * 4 && !wide) return launch_fused<4, 13>(device, s, p, ev0, ev1);
+    if (channels <= 64 * 16 && !wide) return launch_fused<16, 13>(device, s, p, ev0, ev1);
     return launch_fused<64, 13>(device, s, p, ev0, ev1);
 }

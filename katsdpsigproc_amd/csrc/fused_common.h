@@ -1115,6 +1115,215 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
     return xk * FUSED_MAD_NORMAL;
 }
 
+// exact_dev as a function that is CALLED (threshold_wide's rarely taken path must not add
+// its registers to those of the loop around it)
+template <int WIDTH, class Fetch>
+__device__ __noinline__ double exact_dev_call(int c, Fetch fetch)
+{
+    return exact_dev<WIDTH>(c, fetch);
+}
+
+// ---------------------------------------------------------------------------------
+// SumThreshold with up to 8 windows (1 .. 128 channels) for lanes of 64 channels: what
+// threshold_flags<.., MAXK = 8> runs instead of its loop over the windows up to 8 (which
+// sums every window directly, from a second copy of the deviations). Returns the flags.
+//
+// The sums of w consecutive values are built by doubling, S_2s[j] = S_s[j] + S_s[j + s],
+// in float32 over the UNFLAGGED deviations (U, flagged samples count as 0) and, as one
+// byte per position, over the flag bits (N): the host's float64 sum is U* + N thr with
+// U* the exact sum, and it exceeds w thr iff U* > (w - N) thr =: T. U differs from U* by
+// at most (k + 1) 2^-24 (|U| + 2 w nmax), nmax = the baseline's largest downward deviation
+// (k roundings of partial sums and the rounding of the deviations themselves; the sum of
+// the absolute values is at most |U| + 2 w nmax). U > T (1 + 2^-18) + 2^-18 w nmax is
+// therefore a hit, U <= T (1 - 2^-18) - 2^-18 w nmax is none, and the sliver in between --
+// and every window when a threshold is not positive -- is summed again as the host does
+// it, sequentially in float64 from exact deviations. U and N depend on the flags only:
+// they are kept from one window size to the next (one more doubling) unless flags were
+// added in between.
+template <int WIDTH, class Fetch>
+__device__ __forceinline__ unsigned long long threshold_wide(const FusedParams &p,
+                                                             const float (&dev)[64],
+                                                             unsigned long long fl,
+                                                             unsigned long long ge, double t1,
+                                                             bool positive, int lane, int C,
+                                                             Fetch &&fetch)
+{
+    const int c0 = lane * 64;
+    float nmax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 64; j++) nmax = fmaxf(nmax, -dev[j]);
+    nmax = ksp_wave_max(nmax);
+    // U1: the unflagged deviations (flags only grow: maintained from its own previous state,
+    // so that `dev` is not needed again in here -- three arrays of 64 do not fit the
+    // registers, and a spilled one must not be what every rebuild reads)
+    float U[64];
+    unsigned Nb[16];  // byte j % 4 of Nb[j / 4]: flagged samples in the window at j
+#pragma unroll
+    for (int j = 0; j < 64; j++) U[j] = dev[j];
+#pragma unroll
+    for (int q = 0; q < 16; q++) Nb[q] = 0;
+    int lvl = -1;  // U, Nb hold the sums over 2^lvl samples (-1: to be rebuilt from the flags)
+    float umax = 0.0f;  // the baseline's largest unflagged deviation (as of the last rebuild)
+    bool counted = false;  // Nb is kept (some lane has a flag)
+    // one doubling, window s -> 2 s, in place: position j takes j + s, by residue class
+    // r = j mod s in ascending order, so that the addend is still the old value; the last
+    // position of a class takes the next lane's (old) value at r, fetched first
+    auto level = [&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        ksp_static_for<s>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            const float e = __shfl_down(U[r], 1, 64);
+#pragma unroll
+            for (int j = r; j + s < 64; j += s) U[j] += U[j + s];
+            U[r + 64 - s] += e;
+        });
+        if (counted) {
+            if constexpr (s >= 4) {
+                constexpr int sq = s / 4;
+                ksp_static_for<sq>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    const unsigned e = (unsigned)__shfl_down((int)Nb[r], 1, 64);
+#pragma unroll
+                    for (int q = r; q + sq < 16; q += sq) Nb[q] += Nb[q + sq];
+                    Nb[r + 16 - sq] += e;
+                });
+            } else {
+                const unsigned e = (unsigned)__shfl_down((int)Nb[0], 1, 64);
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    Nb[q] += __builtin_amdgcn_alignbyte(q + 1 < 16 ? Nb[(q + 1) % 16] : e, Nb[q], s);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int k = 0; k < p.n_windows; k++) {
+        if (positive && !ksp_any((ge & ~fl) != 0)) break;  // nothing left that could fire
+        const int w = 1 << k;
+        const double scale = k == 0 ? p.scales[0] : k == 1 ? p.scales[1] : k == 2 ? p.scales[2]
+                           : k == 3 ? p.scales[3] : k == 4 ? p.scales[4] : k == 5 ? p.scales[5]
+                           : k == 6 ? p.scales[6] : p.scales[7];
+        const float thrf = (float)(t1 * scale);  // host.py:235
+        const float limf = __fmul_rn(thrf, (float)w);
+        const double limit = (double)limf;  // host.py:242
+        // a window that fires holds an unflagged sample above thr (one whose float32
+        // deviation is at least thr): none in the baseline, nothing to do for this size
+        if (positive && lvl >= 0 && umax < thrf) continue;
+        if (lvl < 0) {
+            counted = ksp_any(fl != 0);
+            {
+                const unsigned f_lo = (unsigned)fl, f_hi = (unsigned)(fl >> 32);
+#pragma unroll
+                for (int j = 0; j < 64; j++)
+                    U[j] = (((j < 32 ? f_lo : f_hi) >> (j & 31)) & 1u) ? 0.0f : dev[j];
+            }
+            float m = U[0];
+#pragma unroll
+            for (int j = 1; j < 64; j++) m = fmaxf(m, U[j]);
+            umax = ksp_wave_max(m);
+            if (counted) {
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    Nb[q] = ((((unsigned)(fl >> (4 * q))) & 0xfu) * 0x00204081u) & 0x01010101u;
+            }
+            lvl = 0;
+            if (positive && umax < thrf) continue;
+        }
+        while (lvl < k) {
+            switch (lvl) {
+            case 0: level(std::integral_constant<int, 1>{}); break;
+            case 1: level(std::integral_constant<int, 2>{}); break;
+            case 2: level(std::integral_constant<int, 4>{}); break;
+            case 3: level(std::integral_constant<int, 8>{}); break;
+            case 4: level(std::integral_constant<int, 16>{}); break;
+            case 5: level(std::integral_constant<int, 32>{}); break;
+            default: level(std::integral_constant<int, 64>{}); break;
+            }
+            lvl++;
+        }
+        // windows that lie inside the band start at channels <= C - w
+        const int nvalid = C - w + 1 - c0;
+        const unsigned long long valid = nvalid >= 64 ? ~0ull : nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1);
+        unsigned long long hits = 0, unsure = valid;
+        if (positive) {
+            unsigned h_lo = 0, h_hi = 0, m_lo = 0, m_hi = 0;
+            const float c = (float)w * nmax * 0x1p-18f;
+            if (counted) {
+                const unsigned wq = (unsigned)w * 0x01010101u;
+                auto one = [&](auto j_, unsigned &h, unsigned &m) {
+                    constexpr int j = decltype(j_)::value;
+                    const unsigned left = wq - Nb[j / 4];  // unflagged samples, per byte
+                    const float rem = (float)((left >> (8 * (j % 4))) & 0xffu);
+                    const float T = rem * thrf;
+                    const float hi = __builtin_fmaf(T, 1.0f + 0x1p-18f, c);
+                    float lo = __builtin_fmaf(T, 1.0f - 0x1p-18f, -c);
+                    lo = (rem == 0.0f) ? __builtin_inff() : lo;  // all flagged: the sum IS the limit
+                    h = 2 * h + (U[j] > hi);
+                    m = 2 * m + (U[j] > lo);
+                };
+                ksp_static_for<32>([&](auto i_) { one(std::integral_constant<int, 31 - decltype(i_)::value>{}, h_lo, m_lo); });
+                ksp_static_for<32>([&](auto i_) { one(std::integral_constant<int, 63 - decltype(i_)::value>{}, h_hi, m_hi); });
+            } else {
+                const float hi = __builtin_fmaf(limf, 1.0f + 0x1p-18f, c);
+                const float lo = __builtin_fmaf(limf, 1.0f - 0x1p-18f, -c);
+#pragma unroll
+                for (int j = 31; j >= 0; j--) {
+                    h_lo = 2 * h_lo + (U[j] > hi);
+                    m_lo = 2 * m_lo + (U[j] > lo);
+                }
+#pragma unroll
+                for (int j = 63; j >= 32; j--) {
+                    h_hi = 2 * h_hi + (U[j] > hi);
+                    m_hi = 2 * m_hi + (U[j] > lo);
+                }
+            }
+            hits = (((unsigned long long)h_hi << 32) | h_lo) & valid;
+            unsure = (((unsigned long long)m_hi << 32) | m_lo) & valid & ~hits;
+        }
+        // the undecided windows, as the host sums them
+        if (ksp_any(unsure != 0)) {
+            const unsigned long long f1 = __shfl_down(fl, 1, 64), f2 = __shfl_down(fl, 2, 64);
+            while (ksp_any(unsure != 0)) {
+                const bool has = unsure != 0;
+                const int j = has ? __ffsll((long long)unsure) - 1 : 0;
+                unsure &= unsure - 1;
+                double s = 0.0;
+                for (int m = 0; m < w; m++) {
+                    const int jj = j + m;
+                    const unsigned long long fw = jj < 64 ? fl : jj < 128 ? f1 : f2;
+                    const bool sub = (fw >> (jj & 63)) & 1;
+                    const double x = exact_dev_call<WIDTH>(c0 + jj, fetch);
+                    s += sub ? (double)thrf : x;
+                }
+                if (has && s > limit) hits |= 1ull << j;
+            }
+            lvl = -1;  // (U and N are not kept across this rarely taken path: registers)
+        }
+        if (!ksp_any(hits != 0)) continue;
+        // dilation: a hit at j flags j .. j + w - 1, up to two lanes on
+        auto suffix_or = [](unsigned long long t) {
+            t |= t >> 1; t |= t >> 2; t |= t >> 4; t |= t >> 8; t |= t >> 16; t |= t >> 32;
+            return t;
+        };
+        unsigned long long add = hits;
+        for (int s = 1; s < w && s < 64; s <<= 1) add |= add << s;
+        unsigned long long h1 = __shfl_up(hits, 1, 64), h2 = __shfl_up(hits, 2, 64);
+        if (lane < 1) h1 = 0;
+        if (lane < 2) h2 = 0;
+        if (w > 64) {
+            add |= h1 ? ~0ull : 0ull;
+            add |= suffix_or(h2 >> 1);
+        } else if (w > 1) {
+            add |= suffix_or(h1 >> (65 - w));
+        }
+        if (ksp_any((add & ~fl) != 0)) {
+            fl |= add;
+            lvl = -1;
+        }
+    }
+    return fl;
+}
+
+
 // ---------------------------------------------------------------------------------
 // Thresholds. Returns the flag mask of the lane's run (bit j: channel c0 + j).
 //
@@ -1124,7 +1333,7 @@ __device__ __forceinline__ double mad_noise(const float (&dev)[R], int lane, dou
 // float64 sum. Windows whose sum is further than that from the limit are decided as
 // the exact arithmetic would decide them; the others (practically never) are summed
 // again from exact deviations.
-template <int R, int WIDTH, class Fetch>
+template <int R, int WIDTH, int MAXK = 4, class Fetch>
 __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams &p,
                                                               const float (&dev)[R], float dmax,
                                                               double noise64, int lane, int C,
@@ -1161,16 +1370,18 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
     }
     const double t1 = p.n_sigma * noise64;  // host.py:252
     // (static indices only: a runtime-indexed array would live in scratch memory)
-    constexpr int MAXW = 4;
+    static_assert(MAXK == 4 || (MAXK == 8 && R == 64), "windows above 8: lanes of 64 channels");
+    constexpr int MAXW = 4;  // windows 1, 2, 4, 8 here; 16 .. 128 in threshold_wide
     float thr[MAXW];
     float thr_min = __builtin_inff();
     bool thr_nan = false;
 #pragma unroll
-    for (int k = 0; k < MAXW; k++) {
-        thr[k] = (float)(t1 * p.scales[k < KSP_MAX_WINDOWS ? k : 0]);  // host.py:235
+    for (int k = 0; k < MAXK; k++) {
+        const float t = (float)(t1 * p.scales[k < KSP_MAX_WINDOWS ? k : 0]);  // host.py:235
+        if (k < MAXW) thr[k < MAXW ? k : 0] = t;
         if (k < p.n_windows) {
-            thr_min = fminf(thr_min, thr[k]);
-            thr_nan |= (thr[k] != thr[k]);
+            thr_min = fminf(thr_min, t);
+            thr_nan |= (t != t);
         }
     }
     // Fast reject (exact): no window can fire unless some sample reaches
@@ -1223,6 +1434,7 @@ __device__ __forceinline__ unsigned long long threshold_flags(const FusedParams 
         (c0 + R <= C) ? (R == 64 ? ~0ull : ((1ull << R) - 1))
                       : (c0 >= C ? 0ull : ((1ull << (C - c0)) - 1));
     if (positive && !__any(((ge & ~gt0) & inband) != 0)) return gt0 & inband;
+    if constexpr (MAXK > 4) return threshold_wide<WIDTH>(p, dev, 0ull, ge, t1, positive, lane, C, fetch);
 
     // General case: some window may hold a weak sample. `hot` = unflagged samples that
     // can still make a window fire (all of them when a threshold is not positive).

@@ -626,12 +626,14 @@ __global__ __launch_bounds__(RING_THREADS) void flagger_ring_kernel(const FusedP
 
 // =================================================================================
 // Can this launch take the ring kernel? (whole band of 4096 channels, complex input, no
-// input flags, at least one whole strip, lane offsets within 32 bits)
+// input flags, at least one whole strip, at most 4 SumThreshold windows, lane offsets within
+// 32 bits)
 inline bool ring_supported(const FusedParams &p, int width)
 {
     return p.channels == 4096 && width % 2 == 1 && width >= 3 && width <= 13 && !p.is_amplitude &&
            p.flags_mode == KSP_FLAGS_NONE && p.deviations == nullptr && p.work != nullptr &&
            p.baselines >= RING_STRIP && (p.vis_stride % 2) == 0 &&
+           (p.threshold_kind != KSP_THRESHOLD_SUM || p.n_windows <= 4) &&
            (size_t)p.vis_stride * 8 * 4096 < 0x7fffff00ull;
 }
 

@@ -51,10 +51,11 @@ def test_abi_version_and_no_device_calls(lib):
     assert lib.ksp_flagger_fused_supported(4096, 5, 4) == 1
     assert lib.ksp_flagger_fused_supported(4096, 25, 4) == 1  # (round 3: widths up to 31)
     assert lib.ksp_flagger_fused_supported(4096, 33, 4) == 0
-    assert lib.ksp_flagger_fused_supported(4096, 13, 5) == 0
+    assert lib.ksp_flagger_fused_supported(4096, 13, 8) == 1  # (round 3: up to 8 windows)
+    assert lib.ksp_flagger_fused_supported(4096, 13, 9) == 0
+    assert lib.ksp_flagger_fused_supported(8192, 13, 5) == 0
     assert lib.ksp_flagger_fused_last_path() == 0  # no launch yet on this thread
     assert lib.ksp_flagger_fused_supported(4096, 12, 4) == 0
-    assert lib.ksp_flagger_fused_supported(4096, 13, 5) == 0
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

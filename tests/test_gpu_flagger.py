@@ -3,6 +3,7 @@ single-pass kernel (bit-identical to FlaggerHost), and the raw C-ABI entry point
 
 import ctypes
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -103,14 +104,24 @@ def check_ring_path(template, command_queue, vis, in_flags, threshold_args, out)
     fn = lean.instantiate(command_queue, vis.shape[0], vis.shape[1], threshold_args=threshold_args)
     fn.ensure_all_bound()
     fn.buffer("vis").set(command_queue, vis)
-    for _ in range(2):  # (twice: the scheduling counters must be left as they were found)
-        fn.buffer("flags").set(command_queue, np.full(vis.shape, 255, np.uint8))
-        fn()
-        path = _lib.call("ksp_flagger_fused_last_path")
-        assert path & 4, f"expected the ring kernel, last path = {path}"
-        assert (path & 1) == (1 if vis.shape[1] % 8 else 0)
-        np.testing.assert_array_equal(fn.buffer("flags").get(command_queue), out["flags"])
-        np.testing.assert_array_equal(fn.buffer("noise").get(command_queue), out["noise"])
+    # (launches of fewer than about 8192 baselines are left to the 4-baseline kernel unless told
+    # otherwise: csrc/flagger_fused.hip)
+    previous = os.environ.get("KSP_FUSED_RING")
+    os.environ["KSP_FUSED_RING"] = "1"
+    try:
+        for _ in range(2):  # (twice: the scheduling counters must be left as they were found)
+            fn.buffer("flags").set(command_queue, np.full(vis.shape, 255, np.uint8))
+            fn()
+            path = _lib.call("ksp_flagger_fused_last_path")
+            assert path & 4, f"expected the ring kernel, last path = {path}"
+            assert (path & 1) == (1 if vis.shape[1] % 8 else 0)
+            np.testing.assert_array_equal(fn.buffer("flags").get(command_queue), out["flags"])
+            np.testing.assert_array_equal(fn.buffer("noise").get(command_queue), out["noise"])
+    finally:
+        if previous is None:
+            del os.environ["KSP_FUSED_RING"]
+        else:
+            os.environ["KSP_FUSED_RING"] = previous
 
 
 class TestSequence:
@@ -627,6 +638,84 @@ class TestFused:
         assert ref_flags.sum() > 0
         np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    @staticmethod
+    def _broad_interference(channels, baselines, seed):
+        """Noise with combs -- every 2nd to 4th channel of a stretch of 20 .. 300 raised by a
+        factor of 1.5 .. 4, which the median filter leaves standing and only sums over many
+        channels find --, a few strong spikes, a stretch longer than the widest window that
+        ends up flagged throughout, and a comb up to the band's end."""
+        rs = np.random.RandomState(seed)
+        vis = inputs.generate_data(channels, baselines, seed=seed + 100)
+        for b in range(baselines):
+            for _ in range(4):
+                length = rs.randint(20, min(300, channels // 2))
+                c = rs.randint(0, channels - length)
+                vis[c:c + length:rs.randint(2, 5), b] *= rs.uniform(1.5, 4.0)
+            vis[rs.randint(0, channels, 3), b] *= rs.uniform(20, 60)
+            if channels >= 600 and b % 3 == 0:
+                c = rs.randint(0, channels - 400)
+                vis[c:c + 300:2, b] *= 40.0  # (across several lanes' runs of 64 channels)
+            if channels > 200 and b % 4 == 1:
+                vis[channels - 70::3, b] *= 3.0
+        return vis
+
+    @pytest.mark.parametrize("n_windows", [5, 6, 7, 8])
+    @pytest.mark.parametrize("channels, baselines, mode, width",
+                             [(4096, 20, "none", 13), (1000, 13, "full", 13), (273, 9, "channel", 5),
+                              (130, 6, "none", 13), (64, 5, "none", 3), (2048, 9, "none", 25)])  # fmt: skip
+    def test_wide_windows(self, n_windows, channels, baselines, mode, width, context,
+                          command_queue, oracle):  # fmt: skip
+        """SumThreshold with 5 .. 8 windows (16 .. 128 channels) in the fused kernel, against
+        the oracle (itself pinned for 6 and 8 windows by goldens of the reference)."""
+        from katsdpsigproc_amd.rfi import device
+
+        vis = self._broad_interference(channels, baselines, seed=n_windows * 10 + width)
+        in_flags = None
+        if mode == "channel":
+            in_flags = inputs.channel_mask(channels)
+        elif mode == "full":
+            in_flags = (np.random.RandomState(5).rand(channels, baselines) < 0.05).astype(np.uint8)
+        bg = device.BackgroundMedianFilterDeviceTemplate(
+            context, width, use_flags=device.BackgroundFlags[mode.upper()])
+        th = device.ThresholdSumDeviceTemplate(context, n_windows=n_windows)
+        template = device.FlaggerDeviceTemplate(bg, device.NoiseEstMADTDeviceTemplate(context, 10240),
+                                                th, fused=True)  # fmt: skip
+        for n_sigma, falloff in ((6.0, 1.5), (11.0, 1.5), (6.0, 1.2)):
+            out = run_fused(template, command_queue, vis, in_flags, n_sigma=n_sigma,
+                            threshold_falloff=falloff)  # fmt: skip
+            ref_flags, ref_noise = oracle.flagger_full(
+                vis, in_flags, width=width, n_sigma=n_sigma, n_windows=n_windows,
+                threshold_falloff=falloff)  # fmt: skip
+            np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+            if channels >= 1000 and falloff == 1.5:
+                # the widest window has found something the narrower ones do not
+                narrow, _ = oracle.flagger_full(vis, in_flags, width=width, n_sigma=n_sigma,
+                                                n_windows=n_windows - 1, threshold_falloff=falloff)  # fmt: skip
+                assert (ref_flags != narrow).sum() > 0
+            np.testing.assert_array_equal(ref_flags, out["flags"])
+
+    def test_wide_windows_degenerate(self, context, command_queue, oracle):
+        """8 windows where the quick decisions do not apply: a threshold that is not positive
+        (n_sigma 0: every window is summed as the host does it), a huge downward deviation
+        (the error bound scales with it) and all-zero baselines."""
+        from katsdpsigproc_amd.rfi import device
+
+        vis = self._broad_interference(300, 6, seed=77)
+        vis[100, 1] = 0.0
+        vis[90:110, 1] *= 1e6
+        vis[100, 1] = 0.0  # deviation of about -1e6 noise units
+        vis[:, 4] = 0.0
+        bg = device.BackgroundMedianFilterDeviceTemplate(context, 13)
+        th = device.ThresholdSumDeviceTemplate(context, n_windows=8)
+        template = device.FlaggerDeviceTemplate(bg, device.NoiseEstMADTDeviceTemplate(context, 10240),
+                                                th, fused=True)  # fmt: skip
+        for n_sigma in (0.0, 3.0):
+            out = run_fused(template, command_queue, vis, n_sigma=n_sigma, threshold_falloff=1.5)
+            ref_flags, ref_noise = oracle.flagger_full(vis, n_sigma=n_sigma, n_windows=8,
+                                                       threshold_falloff=1.5)  # fmt: skip
+            np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
+            np.testing.assert_array_equal(ref_flags, out["flags"])
+
     def test_unsupported_falls_back_to_sequence(self, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
@@ -637,7 +726,9 @@ class TestFused:
                 device.ThresholdSumDeviceTemplate(context, n_windows=6), **kw)
 
         fn = six_windows().instantiate(command_queue, 64, 8, threshold_args=dict(n_sigma=11.0))
-        assert isinstance(fn, device.FlaggerDevice)  # more than 4 windows: kernel per stage
+        assert isinstance(fn, device.FusedFlaggerDevice)  # (round 3: up to 8 windows fuse)
+        fn = six_windows().instantiate(command_queue, 8192, 8, threshold_args=dict(n_sigma=11.0))
+        assert isinstance(fn, device.FlaggerDevice)  # ... but not on bands above 4096 channels
         fn = make_template(context, width=25).instantiate(
             command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
         )
@@ -648,7 +739,7 @@ class TestFused:
         assert isinstance(fn, device.FlaggerDevice)  # beyond the fused kernels' 12288 channels
         with pytest.raises(ValueError):
             six_windows(fused=True).instantiate(
-                command_queue, 64, 8, threshold_args=dict(n_sigma=11.0)
+                command_queue, 8192, 8, threshold_args=dict(n_sigma=11.0)
             )
 
     def test_config3_size_bit_exact(self, context, command_queue, oracle):
