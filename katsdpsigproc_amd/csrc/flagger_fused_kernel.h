@@ -21,7 +21,7 @@
 #endif
 
 // =================================================================================
-template <int R, int WIDTH, int MAXK = 4>
+template <int R, int WIDTH>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const FusedParams p)
 {
     using LY = FusedLayout<R>;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
     if (FUSED_DIAG_STOP(pa) == 3 || FUSED_DIAG_STOP(pa) > 30) return;
 
     const unsigned long long fl =
-        threshold_flags<R, WIDTH, MAXK>(pa, dev, dmax, noise64, lane, C, fetch);
+        threshold_flags<R, WIDTH, (R == 64 ? 8 : 4)>(pa, dev, dmax, noise64, lane, C, fetch);
     stamp(5);
     if (FUSED_DIAG_STOP(pa) == 4) {
         if (fl == 0x123456789abcull && pa.noise) pa.noise[0] = 1.0f;
@@ -174,23 +174,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void flagger_fused_kernel(const F
 }
 
 // =================================================================================
-template <int R, int WIDTH, int MAXK = 4>
+template <int R, int WIDTH>
 inline int launch_fused(int device, hipStream_t s, const FusedParams &p, hipEvent_t ev0,
                         hipEvent_t ev1, bool zero_fill = true)
 {
-    // SumThreshold windows of 16 .. 128 channels (n_windows 5 .. 8): the kernel variant that
-    // carries them (lanes of 64 channels)
-    if constexpr (MAXK == 4 && R == 64) {
-        if (p.threshold_kind == KSP_THRESHOLD_SUM && p.n_windows > 4)
-            return launch_fused<R, WIDTH, 8>(device, s, p, ev0, ev1, zero_fill);
-    }
     using LY = FusedLayout<R>;
     const size_t lds_bytes = LY::LDS_BYTES;
     // all flags start at zero; the kernels only write the (rare) non-zero ones
     if (zero_fill)
         KSP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)(p.channels - 1) * p.flags_stride + p.baselines,
                                  s));
-    auto kern = flagger_fused_kernel<R, WIDTH, MAXK>;
+    auto kern = flagger_fused_kernel<R, WIDTH>;
     // the opt-in to more than 64 KiB of dynamic LDS is per device (one context per
     // device in one process is a supported arrangement, reference doc/user/init.rst:4-6)
     static std::atomic<bool> attr_set[64];

@@ -1246,7 +1246,8 @@ __device__ __forceinline__ unsigned long long threshold_wide(const FusedParams &
         unsigned long long hits = 0, unsure = valid;
         if (positive) {
             unsigned h_lo = 0, h_hi = 0, m_lo = 0, m_hi = 0;
-            const float c = (float)w * nmax * 0x1p-18f;
+            // (+ w 2^-149: a subnormal deviation is rounded by up to 2^-150, not by 2^-24 of itself)
+            const float c = (float)w * nmax * 0x1p-18f + (float)w * 0x1p-149f;
             if (counted) {
                 const unsigned wq = (unsigned)w * 0x01010101u;
                 auto one = [&](auto j_, unsigned &h, unsigned &m) {

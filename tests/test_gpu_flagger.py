@@ -1,6 +1,7 @@
 """GPU parity tests of the flagger: the reference-shaped kernel sequence, the fused
 single-pass kernel (bit-identical to FlaggerHost), and the raw C-ABI entry point."""
 
+import contextlib
 import ctypes
 import hashlib
 import os
@@ -85,6 +86,22 @@ def run_fused(template, command_queue, vis, in_flags=None, **threshold_args):
     return out
 
 
+@contextlib.contextmanager
+def force_ring():
+    """Launches of fewer than about 8192 baselines are left to the 4-baseline kernel unless
+    the environment says otherwise (csrc/flagger_fused.hip): the tests of the ring kernel on
+    small arrays say so."""
+    previous = os.environ.get("KSP_FUSED_RING")
+    os.environ["KSP_FUSED_RING"] = "1"
+    try:
+        yield
+    finally:
+        if previous is None:
+            del os.environ["KSP_FUSED_RING"]
+        else:
+            os.environ["KSP_FUSED_RING"] = previous
+
+
 def check_ring_path(template, command_queue, vis, in_flags, threshold_args, out):
     """Launches that keep the deviations take the 4-baseline kernel; without them a
     4096-channel launch of complex visibilities without input flags (width 13, at least 8
@@ -104,24 +121,15 @@ def check_ring_path(template, command_queue, vis, in_flags, threshold_args, out)
     fn = lean.instantiate(command_queue, vis.shape[0], vis.shape[1], threshold_args=threshold_args)
     fn.ensure_all_bound()
     fn.buffer("vis").set(command_queue, vis)
-    # (launches of fewer than about 8192 baselines are left to the 4-baseline kernel unless told
-    # otherwise: csrc/flagger_fused.hip)
-    previous = os.environ.get("KSP_FUSED_RING")
-    os.environ["KSP_FUSED_RING"] = "1"
-    try:
-        for _ in range(2):  # (twice: the scheduling counters must be left as they were found)
-            fn.buffer("flags").set(command_queue, np.full(vis.shape, 255, np.uint8))
+    for _ in range(2):  # (twice: the scheduling counters must be left as they were found)
+        fn.buffer("flags").set(command_queue, np.full(vis.shape, 255, np.uint8))
+        with force_ring():
             fn()
-            path = _lib.call("ksp_flagger_fused_last_path")
-            assert path & 4, f"expected the ring kernel, last path = {path}"
-            assert (path & 1) == (1 if vis.shape[1] % 8 else 0)
-            np.testing.assert_array_equal(fn.buffer("flags").get(command_queue), out["flags"])
-            np.testing.assert_array_equal(fn.buffer("noise").get(command_queue), out["noise"])
-    finally:
-        if previous is None:
-            del os.environ["KSP_FUSED_RING"]
-        else:
-            os.environ["KSP_FUSED_RING"] = previous
+        path = _lib.call("ksp_flagger_fused_last_path")
+        assert path & 4, f"expected the ring kernel, last path = {path}"
+        assert (path & 1) == (1 if vis.shape[1] % 8 else 0)
+        np.testing.assert_array_equal(fn.buffer("flags").get(command_queue), out["flags"])
+        np.testing.assert_array_equal(fn.buffer("noise").get(command_queue), out["noise"])
 
 
 class TestSequence:
@@ -384,7 +392,8 @@ class TestFused:
         fn.ensure_all_bound()
         assert not fn.slots["deviations"].is_bound()
         fn.buffer("vis").set(command_queue, vis)
-        fn()
+        with force_ring():
+            fn()
         if channels == 4096:
             assert _lib.call("ksp_flagger_fused_last_path") & 4  # nothing optional: the ring kernel
         np.testing.assert_array_equal(ref_flags, fn.buffer("flags").get(command_queue))
