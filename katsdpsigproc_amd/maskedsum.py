@@ -18,24 +18,23 @@ class MaskedSumTemplate:
     use_amplitudes
         Sum amplitudes (float32 result) instead of complex values (complex64 result)
     tuning
-        Accepted and ignored (``size`` of the reference).
+        The kernel's geometry is fixed: ``size`` of the reference is accepted without effect,
+        any other key is a ``ValueError`` (:func:`.tune.fixed_geometry`).
     """
 
-    autotune_version = 1
+    TUNING_KEYS = ("size",)
 
     def __init__(self, context: AbstractContext, use_amplitudes: bool = False,
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
         self.context = context
         self.use_amplitudes = use_amplitudes
-        if tuning is None:
-            tuning = self.autotune(context, use_amplitudes)
-        self.tuning = dict(tuning)
+        self.tuning = tune.fixed_geometry("MaskedSumTemplate", tuning, self.TUNING_KEYS)
         self.kernel = context.native_kernel("ksp_maskedsum_float")
 
     @classmethod
-    @tune.autotuner(test={"size": 256})
     def autotune(cls, context: AbstractContext, use_amplitudes: bool) -> Mapping[str, Any]:
-        return {"size": 16}
+        """Nothing to search (reference maskedsum.py:73 times size)."""
+        return {}
 
     def instantiate(self, command_queue: AbstractCommandQueue, shape: Tuple[int, int],
                     allocator: Optional[accel.AbstractAllocator] = None) -> "MaskedSum":  # fmt: skip

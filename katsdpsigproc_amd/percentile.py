@@ -25,10 +25,12 @@ class Percentile5Template:
     is_amplitude
         True: float32 amplitudes in; False: complex64 in, statistics of ``abs``
     tuning
-        Accepted and ignored (``size``/``wgsy`` of the reference).
+        The kernels' geometry is fixed (a wavefront or a 256-thread workgroup per row, chosen
+        from the number of columns): ``size``/``wgsy`` of the reference are accepted without
+        effect, any other key is a ``ValueError`` (:func:`.tune.fixed_geometry`).
     """
 
-    autotune_version = 8
+    TUNING_KEYS = ("size", "wgsy")
 
     def __init__(self, context: AbstractContext, max_columns: int, is_amplitude: bool = True,
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
@@ -37,15 +39,13 @@ class Percentile5Template:
         self.context = context
         self.max_columns = max_columns
         self.is_amplitude = is_amplitude
-        if tuning is None:
-            tuning = self.autotune(context, max_columns, is_amplitude)
-        self.tuning = dict(tuning)
+        self.tuning = tune.fixed_geometry("Percentile5Template", tuning, self.TUNING_KEYS)
         self.kernel = context.native_kernel("ksp_percentile5_float")
 
     @classmethod
-    @tune.autotuner(test={"size": 64, "wgsy": 4})
     def autotune(cls, context, max_columns: int, is_amplitude: bool) -> Mapping[str, Any]:
-        return {"size": 256, "wgsy": 1}
+        """Nothing to search (reference percentile.py:88-121 times size/wgsy)."""
+        return {}
 
     def instantiate(self, command_queue: AbstractCommandQueue, shape: Tuple[int, int],
                     column_range: Optional[Tuple[int, int]] = None,

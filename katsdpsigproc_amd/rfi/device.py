@@ -435,12 +435,15 @@ class NoiseEstMADTDeviceTemplate(AbstractNoiseEstDeviceTemplate):
         Upper bound on channels per instance (at most 16384: a baseline is held in the
         registers of one 256-work-item workgroup)
     tuning
-        Accepted and ignored (``wgsx`` of the reference).
+        The kernel's geometry is fixed (a wavefront or a 256-thread workgroup per baseline):
+        ``wgsx`` of the reference is accepted without effect, any other key is a ``ValueError``
+        (:func:`.tune.fixed_geometry`).
     """
 
     host_class = host.NoiseEstMADHost
     transposed = True
     MAX_CHANNELS_SUPPORTED = 256 * 64
+    TUNING_KEYS = ("wgsx",)
 
     def __init__(self, context: AbstractContext, max_channels: int,
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
@@ -448,15 +451,13 @@ class NoiseEstMADTDeviceTemplate(AbstractNoiseEstDeviceTemplate):
             raise ValueError(f"max_channels exceeds {self.MAX_CHANNELS_SUPPORTED}")
         self.context = context
         self.max_channels = max_channels
-        if tuning is None:
-            tuning = self.autotune(context, max_channels)
-        self.tuning = dict(tuning)
+        self.tuning = tune.fixed_geometry("NoiseEstMADTDeviceTemplate", tuning, self.TUNING_KEYS)
         self.kernel = context.native_kernel("ksp_madnz_t")
 
     @classmethod
-    @tune.autotuner(test={"wgsx": 128})
     def autotune(cls, context: AbstractContext, max_channels: int) -> Mapping[str, Any]:
-        return {"wgsx": 256}
+        """Nothing to search (reference rfi/device.py:523 times wgsx)."""
+        return {}
 
     def instantiate(self, command_queue: AbstractCommandQueue, channels: int, baselines: int,
                     allocator: Optional[AbstractAllocator] = None) -> "NoiseEstMADTDevice":  # fmt: skip
@@ -540,24 +541,25 @@ class ThresholdHostFromDevice(host.AbstractThresholdHost):
 
 class ThresholdSimpleDeviceTemplate(AbstractThresholdDeviceTemplate):
     """Independent per-sample threshold, either memory order
-    (reference rfi/device.py:654-720). `tuning` is accepted and ignored."""
+    (reference rfi/device.py:654-720). The kernel's geometry is fixed: ``wgsx``/``wgsy`` of the
+    reference are accepted in `tuning` without effect, any other key is a ``ValueError``
+    (:func:`.tune.fixed_geometry`)."""
 
     host_class = host.ThresholdSimpleHost
+    TUNING_KEYS = ("wgsx", "wgsy")
 
     def __init__(self, context: AbstractContext, transposed: bool, flag_value: int = 1,
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
-        if tuning is None:
-            tuning = self.autotune(context)
         self.context = context
         self.transposed = transposed
         self.flag_value = flag_value
-        self.tuning = dict(tuning)
+        self.tuning = tune.fixed_geometry("ThresholdSimpleDeviceTemplate", tuning, self.TUNING_KEYS)
         self.kernel = context.native_kernel("ksp_threshold_simple")
 
     @classmethod
-    @tune.autotuner(test={"wgsx": 32, "wgsy": 4})
     def autotune(cls, context: AbstractContext) -> Mapping[str, Any]:
-        return {"wgsx": 256, "wgsy": 1}
+        """Nothing to search (reference rfi/device.py:707 times wgsx/wgsy)."""
+        return {}
 
     def instantiate(self, command_queue: AbstractCommandQueue, channels: int, baselines: int,
                     n_sigma: float,

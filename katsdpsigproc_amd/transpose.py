@@ -21,11 +21,12 @@ class TransposeTemplate:
         C name of the element type. Unused (kernels are not generated from source) but
         accepted so that reference call sites work unchanged (transpose.py:58-64).
     tuning
-        Accepted and ignored: the 64x64 LDS tile of the gfx950 kernel is fixed
-        (``block``/``vtx``/``vty`` of the reference have no counterpart).
+        The 64x64 LDS tile of the gfx950 kernel is fixed: ``block``/``vtx``/``vty`` of the
+        reference are accepted without effect, any other key is a ``ValueError``
+        (:func:`.tune.fixed_geometry`).
     """
 
-    autotune_version = 1
+    TUNING_KEYS = ("block", "vtx", "vty")
 
     def __init__(self, context: AbstractContext, dtype, ctype: str = "",
                  tuning: Optional[Mapping[str, Any]] = None) -> None:  # fmt: skip
@@ -34,15 +35,13 @@ class TransposeTemplate:
         self.ctype = ctype
         if self.dtype.itemsize not in (1, 2, 4, 8, 16):
             raise ValueError(f"unsupported element size {self.dtype.itemsize}")
-        if tuning is None:
-            tuning = self.autotune(context, dtype, ctype)
-        self.tuning = dict(tuning)
+        self.tuning = tune.fixed_geometry("TransposeTemplate", tuning, self.TUNING_KEYS)
         self.kernel = context.native_kernel("ksp_transpose")
 
     @classmethod
-    @tune.autotuner(test={"block": 8, "vtx": 2, "vty": 3})
     def autotune(cls, context: AbstractContext, dtype, ctype: str) -> Mapping[str, Any]:
-        return {"block": 16, "vtx": 4, "vty": 4}
+        """Nothing to search (reference transpose.py:87-108 times block/vtx/vty)."""
+        return {}
 
     def instantiate(self, command_queue: AbstractCommandQueue, shape: Tuple[int, int],
                     allocator: Optional[accel.AbstractAllocator] = None) -> "Transpose":  # fmt: skip

@@ -246,3 +246,22 @@ def autotune(generate: Callable[..., Optional[Callable[[int], float]]], time_lim
             raise failure
         raise ValueError("No options to test")
     return best
+
+
+def fixed_geometry(what: str, tuning, reference_keys):
+    """`tuning=` of an operation whose gfx950 kernel has ONE launch geometry.
+
+    The reference tunes workgroup shapes of kernels it generates from source (`reference_keys`
+    names its parameters); the hand-written kernel behind `what` has nothing to choose. A
+    caller's values for the reference's keys are therefore accepted -- call sites keep working --
+    and have no effect; any other key is a mistake and raises ``ValueError``. Returns the
+    mapping to store as ``template.tuning``: what the caller passed, or ``{}`` (nothing was
+    tuned, nothing is cached)."""
+    if tuning is None:
+        return {}
+    unknown = sorted(set(tuning) - set(reference_keys))
+    if unknown:
+        raise ValueError(
+            f"{what}: unknown tuning parameter(s) {unknown}. Its kernel has a fixed geometry; only "
+            f"the reference's {sorted(reference_keys)} are accepted, without effect")
+    return dict(tuning)

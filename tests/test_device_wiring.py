@@ -248,3 +248,24 @@ def test_primitive_ops(context, queue):
 def test_accel_build_and_context_errors():
     with pytest.raises(FileNotFoundError):
         accel.render_template("x.hip.in")
+
+
+def test_fixed_geometry_tuning(context):
+    """Operations whose kernel has one geometry: the reference's tuning keys are accepted
+    (and change nothing), anything else is an error; nothing pretends to have been tuned."""
+    from katsdpsigproc_amd import maskedsum, percentile, transpose
+    from katsdpsigproc_amd.rfi import device
+
+    cases = [
+        (lambda **kw: transpose.TransposeTemplate(context, np.float32, "float", **kw), {"block": 8, "vtx": 2, "vty": 3}),
+        (lambda **kw: percentile.Percentile5Template(context, 4096, **kw), {"size": 64, "wgsy": 4}),
+        (lambda **kw: maskedsum.MaskedSumTemplate(context, **kw), {"size": 256}),
+        (lambda **kw: device.NoiseEstMADTDeviceTemplate(context, 4096, **kw), {"wgsx": 128}),
+        (lambda **kw: device.ThresholdSimpleDeviceTemplate(context, False, **kw), {"wgsx": 32, "wgsy": 4}),
+    ]  # fmt: skip
+    for make, reference_tuning in cases:
+        assert make().tuning == {}
+        assert make(tuning=reference_tuning).tuning == reference_tuning
+        with pytest.raises(ValueError, match="fixed geometry"):
+            make(tuning={"wavefronts": 2})
+    assert transpose.TransposeTemplate.autotune(context, np.float32, "float") == {}
