@@ -36,16 +36,32 @@ for MODE in NONE CHANNEL; do
   FLAGS=$MODE N=300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$MODE -o k --output-format csv -- python3 $R/tools/run_fused.py > /tmp/kt_$MODE.log 2>&1
   cp $(find /tmp/kt_$MODE -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$MODE.csv
 done
+# the long-band kernels (reference presets kat7 / big, scripts/rfiflagtest.py:190-195: 8192 and
+# 10240 channels; the number of samples of config 3), the ring kernel on an RFI-laden block, and
+# the 4-baseline kernel with 8 windows: instruction and traffic counters, kernel durations
+for CASE in "L8192 8192 4096 0" "L10240 10240 3276 0" "RFI 4096 32768 1"; do
+  set -- $CASE
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
+    i=$((i+1))
+    rm -rf /tmp/pl_$i
+    CH=$2 BL=$3 RFI=$4 N=3 rocprofv3 --kernel-trace --pmc $set -d /tmp/pl_$i -o p --output-format csv -- python3 $R/tools/run_fused.py > /tmp/pl_$i.log 2>&1
+    cp $(find /tmp/pl_$i -name "*counter_collection.csv" | head -1) $OUT/pmc_$1_pass$i.csv
+  done
+  rm -rf /tmp/kl
+  CH=$2 BL=$3 RFI=$4 N=200 rocprofv3 --kernel-trace --stats -d /tmp/kl -o k --output-format csv -- python3 $R/tools/run_fused.py > /tmp/kl.log 2>&1
+  cp $(find /tmp/kl -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$1.csv
+done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
 summary = {}
-for mode in ("NONE", "CHANNEL"):
+for mode in ("NONE", "CHANNEL", "L8192", "L10240", "RFI"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(out + f"/pmc_{mode}_pass*.csv")):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            k = "fused" if ("flagger_ring" in name or "flagger_fused" in name) else ("fill" if "fillBuffer" in name else None)
+            k = "fused" if ("flagger_ring" in name or "flagger_fused" in name or "flagger_long" in name) else ("fill" if "fillBuffer" in name else None)
             if k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 acc[k].setdefault("__kernel__", []).append(name.split("(")[0])

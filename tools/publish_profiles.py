@@ -14,7 +14,10 @@ tag, ver = sys.argv[1], sys.argv[2]
 src = os.path.join(root, "gpurun_out", f"profiles_{tag}")
 rnd = tag[:3]
 for name in ("bench_kernel_stats.csv", "bench_default_kernel_stats.csv", "kernel_stats_NONE.csv",
-             "kernel_stats_CHANNEL.csv"):
+             "kernel_stats_CHANNEL.csv", "kernel_stats_L8192.csv", "kernel_stats_L10240.csv",
+             "kernel_stats_RFI.csv"):
+    if not os.path.exists(os.path.join(src, name)):
+        continue
     shutil.copy(os.path.join(src, name),
                 os.path.join(root, "profiles", f"{rnd}_{name[:-4]}_{ver}.csv"))
 shutil.copy(os.path.join(src, "pmc_summary.json"),
@@ -41,6 +44,13 @@ for mode in ("NONE", "CHANNEL"):
     hit = f["TCC_HIT_sum"] / (f["TCC_HIT_sum"] + f["TCC_MISS_sum"])
     print(f"{mode}: HBM {entries[-1]['hbm_bytes_per_launch'] / 1e9:.3f} GB/launch; L2 hit rate {hit:.3f}; "
           f"VALU instr {f['SQ_INSTS_VALU']:.4g} ({f['SQ_INSTS_VALU'] * 64 / (4096 * 32768):.1f} per sample); "
+          f"VALU active {f['SQ_ACTIVE_INST_VALU'] * 4 / (f['SQ_BUSY_CYCLES'] / 32 * 1024):.2f} of SQ busy")
+for case, (channels, baselines) in (("L8192", (8192, 4096)), ("L10240", (10240, 3276)), ("RFI", (4096, 32768))):
+    if case not in s or "fused" not in s[case]:
+        continue
+    f = s[case]["fused"]
+    print(f"{case}: {f.get('__kernel__')}: FETCH {f['FETCH_SIZE'] * 2048 / 1e9:.3f} GB, WRITE "
+          f"{f['WRITE_SIZE'] * 1024 / 1e9:.3f} GB, VALU {f['SQ_INSTS_VALU'] * 64 / (channels * baselines):.1f} per sample, "
           f"VALU active {f['SQ_ACTIVE_INST_VALU'] * 4 / (f['SQ_BUSY_CYCLES'] / 32 * 1024):.2f} of SQ busy")
 json.dump(entries, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
 for name in ("bench_kernel_stats.csv", "kernel_stats_NONE.csv", "kernel_stats_CHANNEL.csv"):
