@@ -665,8 +665,11 @@ def main() -> int:
             "roofline": {
                 "bound": "hbm",
                 "kernel": "sequence" if args.sequence
-                          else "flagger_ring_kernel (persistent, 8-baseline strips) + zero-fill of"
-                               " flags (one step)",
+                          else ("flagger_fused_kernel (4-baseline strips: a channel mask, or the"
+                                " deviations output, rules the ring kernel out) + zero-fill of flags"
+                                " (one step)" if use_dist or args.keep_deviations
+                                else "flagger_ring_kernel (persistent, 8-baseline strips) + zero-fill"
+                                     " of flags (one step)"),
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "GB/s",
