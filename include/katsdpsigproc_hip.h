@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KSP_ABI_VERSION 4
+#define KSP_ABI_VERSION 5
 
 /* BackgroundFlags (reference: rfi/device.py:40-46) */
 #define KSP_FLAGS_NONE 0
@@ -196,10 +196,16 @@ int ksp_flagger_fused_supported(int channels, int width, int n_windows);
  * 2 = flagger_long_kernel (4097-12288 channels),
  * 4 = flagger_ring_kernel (persistent, strips of 8 baselines, 4096 channels, complex input
  *     without input flags, no deviations output, at most 4 windows; chosen from about 4
- *     strips per compute unit on, or whenever possible / never with KSP_FUSED_RING=1 / 0 in
- *     the environment); 5 = ring kernel plus the 4-baseline kernel for a remainder of fewer
- *     than 8 baselines. */
+ *     strips per compute unit on, see ksp_flagger_fused_ring_mode); 5 = ring kernel plus the
+ *     4-baseline kernel for a remainder of fewer than 8 baselines. */
 int ksp_flagger_fused_last_path(void);
+
+/* Which launches of the calling thread take the persistent ring kernel where it applies
+ * (no reference counterpart; tests and diagnostics): 0 = those with at least 4 strips of 8
+ * baselines per compute unit (the default), 1 = all, -1 = none. The initial value comes from
+ * KSP_FUSED_RING=1 / 0 in the environment if set. Returns the previous mode; any other
+ * argument only queries. */
+int ksp_flagger_fused_ring_mode(int mode);
 
 /* Self-tests of the arithmetic building blocks (no reference counterpart; they exist
  * so that the test-suite can pin device arithmetic against IEEE / numpy results).

@@ -14,7 +14,7 @@ from ctypes import c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_native", "libkatsdpsigproc_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -95,6 +95,7 @@ SIGNATURES = {
     ],
     "ksp_flagger_fused_supported": [c_int, c_int, c_int],
     "ksp_flagger_fused_last_path": [],
+    "ksp_flagger_fused_ring_mode": [c_int],
     "ksp_rtc_compile": [
         c_int, c_char_p, POINTER(c_char_p), c_int, POINTER(c_void_p), c_char_p, c_size_t
     ],
@@ -119,7 +120,8 @@ _OTHER = {
 }
 
 #: functions whose int return value is a result, not an error code
-_VALUE_RETURN = {"ksp_flagger_fused_supported", "ksp_flagger_fused_last_path"}
+_VALUE_RETURN = {"ksp_flagger_fused_supported", "ksp_flagger_fused_last_path",
+                 "ksp_flagger_fused_ring_mode"}
 
 
 def declared_symbols():

@@ -78,6 +78,23 @@ extern "C" int ksp_flagger_fused_profile(void *start_event, void *stop_event)
 
 extern "C" int ksp_flagger_fused_last_path(void) { return g_last_path; }
 
+// ring kernel: 0 = by size, 1 = whenever it applies, -1 = never; per thread, as the launch is
+static thread_local int g_ring_mode = 2;  // (2: not yet taken from the environment)
+static int ring_mode()
+{
+    if (g_ring_mode == 2) {
+        const char *e = getenv("KSP_FUSED_RING");
+        g_ring_mode = e == nullptr ? 0 : (e[0] == '1' ? 1 : -1);
+    }
+    return g_ring_mode;
+}
+extern "C" int ksp_flagger_fused_ring_mode(int mode)
+{
+    const int before = ring_mode();
+    if (mode >= -1 && mode <= 1) g_ring_mode = mode;
+    return before;
+}
+
 extern "C" int ksp_flagger_fused_supported(int channels, int width, int n_windows)
 {
     if (n_windows < 1 || n_windows > KSP_MAX_WINDOWS) return 0;
@@ -170,10 +187,10 @@ extern "C" int ksp_flagger_fused(int device, void *stream, const void *vis,
     // 4-baseline kernel.
     // It pays from about 4 strips per workgroup on (measured, tools/time_ring_sizes.py: 0.089 ms
     // against 0.065 at 4096 baselines, 0.133 = 0.132 at 8192, 0.218 against 0.236 at 16384,
-    // 0.384 against 0.431 at 32768); KSP_FUSED_RING=1 / 0 (tests, diagnostics) forces the choice.
-    static const bool no_ring = getenv("KSP_FUSED_NO_RING") != nullptr;
-    const char *force = getenv("KSP_FUSED_RING");
-    const bool want_ring = force != nullptr ? force[0] == '1' : (!no_ring && baselines / 8 >= 4 * n_cu);
+    // 0.384 against 0.431 at 32768); ksp_flagger_fused_ring_mode (tests, diagnostics; initial
+    // value from KSP_FUSED_RING=1 / 0 in the environment) forces the choice.
+    const int mode = ring_mode();
+    const bool want_ring = mode != 0 ? mode > 0 : baselines / 8 >= 4 * n_cu;
     if (want_ring && width == 13 && ksp_ring_supported(p, width)) {
         // (Letting the ring kernel zero-fill `flags` itself -- write-through stores beside the
         // first strip's loads, a completion counter before the first flag byte -- was built

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_abi_version_and_no_device_calls(lib):
     from katsdpsigproc_amd import _lib
 
-    assert lib.ksp_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.ksp_abi_version() == _lib.ABI_VERSION == 5
     count = ctypes.c_int(-1)
     assert lib.ksp_device_count(ctypes.byref(count)) == 0
     assert count.value >= 0  # 0 in the CPU container
@@ -55,6 +55,9 @@ def test_abi_version_and_no_device_calls(lib):
     assert lib.ksp_flagger_fused_supported(4096, 13, 9) == 0
     assert lib.ksp_flagger_fused_supported(8192, 13, 5) == 0
     assert lib.ksp_flagger_fused_last_path() == 0  # no launch yet on this thread
+    before = lib.ksp_flagger_fused_ring_mode(1)
+    assert before in (-1, 0, 1) and lib.ksp_flagger_fused_ring_mode(7) == 1  # (7: query only)
+    assert lib.ksp_flagger_fused_ring_mode(before) == 1
     assert lib.ksp_flagger_fused_supported(4096, 12, 4) == 0
 
 

@@ -4,7 +4,6 @@ single-pass kernel (bit-identical to FlaggerHost), and the raw C-ABI entry point
 import contextlib
 import ctypes
 import hashlib
-import os
 
 import numpy as np
 import pytest
@@ -89,17 +88,15 @@ def run_fused(template, command_queue, vis, in_flags=None, **threshold_args):
 @contextlib.contextmanager
 def force_ring():
     """Launches of fewer than about 8192 baselines are left to the 4-baseline kernel unless
-    the environment says otherwise (csrc/flagger_fused.hip): the tests of the ring kernel on
-    small arrays say so."""
-    previous = os.environ.get("KSP_FUSED_RING")
-    os.environ["KSP_FUSED_RING"] = "1"
+    told otherwise (ksp_flagger_fused_ring_mode): the tests of the ring kernel on small arrays
+    say so."""
+    from katsdpsigproc_amd import _lib
+
+    previous = _lib.call("ksp_flagger_fused_ring_mode", 1)
     try:
         yield
     finally:
-        if previous is None:
-            del os.environ["KSP_FUSED_RING"]
-        else:
-            os.environ["KSP_FUSED_RING"] = previous
+        _lib.call("ksp_flagger_fused_ring_mode", previous)
 
 
 def check_ring_path(template, command_queue, vis, in_flags, threshold_args, out):

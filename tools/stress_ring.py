@@ -48,7 +48,7 @@ for r in range(rounds):
         fn.buffer("vis").set(q, vis)
         out = {}
         for ring in ("1", "0"):
-            os.environ["KSP_FUSED_RING"] = ring
+            _lib.call("ksp_flagger_fused_ring_mode", 1 if ring == "1" else -1)
             for rep in range(3 if ring == "1" else 1):
                 fn.buffer("flags").set(q, np.full((C, B), 255, np.uint8))
                 fn()
@@ -69,6 +69,6 @@ for r in range(rounds):
                   % (r, pad, len(d), d[:1].tolist(), int((out["1"][1] != out["0"][1]).sum())))
         print("round %d (kind %d) pad %2d: flagged %.4f  %s" % (r, kind, pad, float((out["1"][0] != 0).mean()),
                                                               "same" if same else "DIFFERENT"), flush=True)
-del os.environ["KSP_FUSED_RING"]
+_lib.call("ksp_flagger_fused_ring_mode", 0)
 print("stress_ring: %d mismatches" % bad)
 sys.exit(1 if bad else 0)
