@@ -722,6 +722,34 @@ class TestFused:
             np.testing.assert_array_equal(ref_noise.astype(np.float32), out["noise"])
             np.testing.assert_array_equal(ref_flags, out["flags"])
 
+    def test_ring_kernel_chosen_by_size(self, context, command_queue):
+        """Left alone (ksp_flagger_fused_ring_mode 0), a 4096-channel launch without input flags
+        takes the ring kernel from 4 strips of 8 baselines per compute unit on, the 4-baseline
+        kernel below; the forced modes override that either way."""
+        from katsdpsigproc_amd import _lib
+
+        props = context.device
+        n_cu = getattr(props, "compute_units", None) or 256
+        template = make_template(context, keep_deviations=False)
+        rs = np.random.RandomState(3)
+        tile = (rs.standard_normal((4096, 64)) + 1j * rs.standard_normal((4096, 64))).astype(np.complex64)
+        for baselines, expect_ring in ((32 * n_cu, True), (32 * n_cu - 8, False)):
+            fn = template.instantiate(command_queue, 4096, baselines, threshold_args={"n_sigma": 11.0})
+            fn.ensure_all_bound()
+            fn.buffer("vis").set(command_queue, np.tile(tile, (1, baselines // 64 + 1))[:, :baselines])
+            previous = _lib.call("ksp_flagger_fused_ring_mode", 0)
+            try:
+                fn()
+                assert bool(_lib.call("ksp_flagger_fused_last_path") & 4) == expect_ring
+                auto = fn.buffer("flags").get(command_queue), fn.buffer("noise").get(command_queue)
+                _lib.call("ksp_flagger_fused_ring_mode", -1 if expect_ring else 1)
+                fn()
+                assert bool(_lib.call("ksp_flagger_fused_last_path") & 4) != expect_ring
+                np.testing.assert_array_equal(fn.buffer("flags").get(command_queue), auto[0])
+                np.testing.assert_array_equal(fn.buffer("noise").get(command_queue), auto[1])
+            finally:
+                _lib.call("ksp_flagger_fused_ring_mode", previous)
+
     def test_unsupported_falls_back_to_sequence(self, context, command_queue):
         from katsdpsigproc_amd.rfi import device
 
